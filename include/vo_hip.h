@@ -1,0 +1,201 @@
+/*
+ * vo_hip.h -- C ABI of libvo_hip.so: the MI355X (gfx950) implementation of the per-frame hot path
+ * of giuliano-97/visual_odometry.  Plain pointers and sizes only; every entry point returns an int
+ * status (0 = ok, < 0 = error, see vo_strerror) and never throws or aborts.
+ *
+ * The reference is MATLAB; the binding a maintainer adds is a MEX gateway per operator (mex/ gateways,
+ * INTEGRATION.md) that passes mxGetData pointers straight through:
+ *
+ *   vo_klt_track            <- KLTTracker.track                  modules/KLTTracker.m:22-41
+ *   vo_select_candidates    <- selectCandidateKeypoints          modules/selectCandidateKeypoints.m:1-36
+ *   vo_harris_response,     <- harris / selectKeypoints          old/harris.m:1-25, old/selectKeypoints.m:1-16
+ *   vo_select_keypoints_greedy
+ *   vo_triangulate_candidates <- per-candidate loop body         modules/VisualOdometry.m:87-113,
+ *                                                                modules/candidateTriangulation.m:37-57
+ *   vo_angle_deg            <- calculateAngleDeg                 utils/calculateAngleDeg.m:1-11
+ *   vo_in_front             <- isInFrontOfCamera                 modules/isInFrontOfCamera.m:1-12
+ *   vo_p3p_ransac           <- estimateWorldCameraPose call      modules/VisualOdometry.m:285-289,
+ *                              (P3P + RANSAC/MSAC)               old/ransacLocalization.m:1-147, old/p3p.m:41
+ *   vo_reproj_error         <- computeReprojectionError          modules/VisualOdometry.m:48-61
+ *
+ * Layout (vo_layout): col_major = 1 is MATLAB's memory layout for EVERYTHING passed in the call
+ * (H x W column-major images, N x 2 / N x 3 column-major point arrays, column-major 4 x 3 poses);
+ * col_major = 0 is C / numpy row-major for everything.  index_base is 1 for MATLAB pixel
+ * coordinates (pixel centres at 1..W), 0 for zero-based.  K is always 9 doubles holding the usual
+ * 3 x 3 intrinsic matrix row-major, which is byte-for-byte MATLAB's column-major
+ * cameraParams.IntrinsicMatrix (= K^T, utils/dataLoaderKitti.m:50-53).
+ * Pose = 4 x 3 [R_WC; t_WC] (modules/VisualOdometry.m:318).
+ *
+ * Ownership: the caller owns every buffer; the library owns device memory inside vo_ctx.
+ * Threading: one vo_ctx per thread/GPU; calls on one ctx must be serialised by the caller.
+ * There is NO CPU fallback: without a HIP device vo_ctx_create fails with VO_ERR_NO_DEVICE.
+ */
+#ifndef VO_HIP_H
+#define VO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vo_ctx vo_ctx;
+
+enum {
+    VO_OK = 0,
+    VO_ERR_NO_DEVICE = -1,
+    VO_ERR_BAD_ARG = -2,
+    VO_ERR_HIP = -3,
+    VO_ERR_OOM = -4,
+    VO_ERR_UNSUPPORTED = -5
+};
+
+typedef struct {
+    int col_major;  /* 1 = MATLAB layout, 0 = row-major */
+    int index_base; /* 1 = MATLAB pixel coordinates, 0 = zero-based */
+} vo_layout;
+
+/* modules/KLTTracker.m:11-14 (defaults 4 / 2 / [41 41] / 50); eps is the LK stop threshold */
+typedef struct {
+    int levels;
+    double max_bidir_err; /* < 0 disables the backward pass */
+    int block_h, block_w; /* BlockSize = [height width], odd */
+    int max_iters;
+    double eps;           /* pixels; 0 -> 0.01 */
+} vo_klt_opts;
+
+enum { VO_SCORER_MINEIGEN = 0, VO_SCORER_HARRIS = 1 };
+
+/* modules/selectCandidateKeypoints.m:13-16 (+ scorer switch: live code is min-eigen, north_star
+ * and old/harris.m name Harris) */
+typedef struct {
+    double min_distance;
+    double min_quality;
+    int filter_size; /* Gaussian window (min-eigen) / patch size (Harris), odd, <= 15 */
+    int keep;        /* CandidatesToKeep */
+    int scorer;
+    double kappa;    /* Harris only */
+} vo_sel_opts;
+
+/* modules/VisualOdometry.m:285-289 options + reproducibility controls */
+typedef struct {
+    int num_hyp;          /* MaxNumTrials */
+    double max_reproj_err;/* MaxReprojectionError, pixels */
+    double confidence;    /* (0,1) adaptive stop with sequential-RANSAC semantics; <= 0: use all */
+    uint64_t seed;        /* Philox4x32-10 key of the hypothesis stream */
+    int mode;             /* 0 = inlier count (old/ransacLocalization.m:86-111), 1 = MSAC cost */
+    int min_inliers;      /* old/ransacLocalization.m:102 */
+} vo_ransac_opts;
+
+typedef struct {
+    int status;      /* 0 ok, 1 fewer than 4 points, 2 no hypothesis reached min_inliers */
+    int best_hyp, best_sol, trials_used, num_inliers;
+} vo_ransac_info;
+
+const char* vo_strerror(int code);
+int vo_version(void);
+
+/* ---- context ---- */
+int vo_ctx_create(int device, vo_ctx** out);
+void vo_ctx_destroy(vo_ctx* ctx);
+/* run the library's kernels on a caller-owned hipStream_t (NULL restores the ctx-owned stream) */
+int vo_ctx_set_stream(vo_ctx* ctx, void* hip_stream);
+void* vo_ctx_get_stream(vo_ctx* ctx);
+int vo_ctx_sync(vo_ctx* ctx);
+const char* vo_ctx_last_error(vo_ctx* ctx);
+/* counters: [0] LK iterations executed (window passes), [1] keypoints tracked, [2] LK template
+ * set-ups (level x direction x point), [3] hypotheses scored */
+int vo_ctx_read_counters(vo_ctx* ctx, uint64_t out[4], int reset);
+/* HIP-event stopwatch on the ctx stream (bench.py's live kernel timing) */
+int vo_timer_start(vo_ctx* ctx);
+int vo_timer_stop_ms(vo_ctx* ctx, float* ms);
+
+/* ==== host-pointer entry points (what the MEX gateways bind) ==== */
+
+/* KLTTracker.track, modules/KLTTracker.m:22-41.  pts: N x 2 [x y]; outputs follow the class of
+ * the input points (pts_is_double).  N = 0 returns VO_OK and touches nothing (:33-36). */
+int vo_klt_track(vo_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int H, int W, vo_layout lay,
+                 const void* pts_xy, int N, int pts_is_double, const vo_klt_opts* opts,
+                 void* out_pts_xy, uint8_t* out_valid, void* out_scores);
+
+/* selectCandidateKeypoints, modules/selectCandidateKeypoints.m:1-36.  existing: N_exist x 2.
+ * out_xy: room for keep x 2 floats, written as an M x 2 array in the chosen layout (M rows);
+ * out_linear_idx (optional): 0-based linear memory index of each selected pixel;
+ * out_metric (optional): corner metric.  *out_M = M <= keep. */
+int vo_select_candidates(vo_ctx* ctx, const uint8_t* img, int H, int W, vo_layout lay,
+                         const void* existing_xy, int N_exist, int existing_is_double,
+                         const vo_sel_opts* opts, float* out_xy, int32_t* out_linear_idx,
+                         double* out_metric, int* out_M);
+
+/* old/harris.m:1-25 (scores, H x W doubles in the image's layout) */
+int vo_harris_response(vo_ctx* ctx, const uint8_t* img, int H, int W, vo_layout lay, int patch_size,
+                       double kappa, double* out_scores);
+/* corner response of either scorer (VO_SCORER_*), same output shape as vo_harris_response */
+int vo_corner_response(vo_ctx* ctx, const uint8_t* img, int H, int W, vo_layout lay, int scorer,
+                       int filter_size, double kappa, double* out_scores);
+/* old/selectKeypoints.m:1-16: greedy top-num with (2r+1)^2 suppression on a score image;
+ * out_rc: 2 x num [row; col] (column-major) in index_base coordinates */
+int vo_select_keypoints_greedy(vo_ctx* ctx, const double* scores, int H, int W, vo_layout lay, int num,
+                               int r, int32_t* out_rc);
+
+/* modules/VisualOdometry.m:87-113 batched: first_xy / curr_xy C x 2, first_poses P x (4x3),
+ * first_pose_idx (optional, C entries into the pose table; NULL: P == C, identity),
+ * curr_pose 4x3, K.  Outputs: out_X C x 3, out_reproj C (mean over the two views),
+ * out_angle_deg C (calculateAngleDeg), out_valid C (positive depth in both views). */
+int vo_triangulate_candidates(vo_ctx* ctx, vo_layout lay, const double* first_xy, const double* curr_xy,
+                              const double* first_poses, int P, const int32_t* first_pose_idx, int C,
+                              const double* curr_pose, const double* K, double* out_X,
+                              double* out_reproj, double* out_angle_deg, uint8_t* out_valid);
+
+/* utils/calculateAngleDeg.m:1-11, batched over n landmarks (n x 3) */
+int vo_angle_deg(vo_ctx* ctx, vo_layout lay, const double* landmarks, int n, const double* pose0,
+                 const double* pose1, double* out_angle_deg);
+/* modules/isInFrontOfCamera.m:1-12: cam_mat 4 x 3, points n x 3 */
+int vo_in_front(vo_ctx* ctx, vo_layout lay, const double* cam_mat, const double* points, int n,
+                uint8_t* out_valid);
+/* modules/VisualOdometry.m:48-61 */
+int vo_reproj_error(vo_ctx* ctx, vo_layout lay, const double* keypoints_xy, const double* landmarks,
+                    int n, const double* pose, const double* K, double* out_err);
+
+/* modules/VisualOdometry.m:285-289 / old/ransacLocalization.m.  img_pts M x 2, world_pts M x 3.
+ * sample_idx (optional): num_hyp x 3 zero-based indices, row-major, overriding the seeded stream.
+ * Outputs: R_wc (3x3 world orientation, in the chosen layout), t_wc (world location) -- i.e.
+ * pose = [R_wc; t_wc]; inliers M; info.  hyp_counts / hyp_costs (optional, num_hyp x 4). */
+int vo_p3p_ransac(vo_ctx* ctx, vo_layout lay, const double* img_pts, const double* world_pts, int M,
+                  const double* K, const vo_ransac_opts* opts, const int32_t* sample_idx,
+                  double* out_R_wc, double* out_t_wc, uint8_t* out_inliers, vo_ransac_info* info,
+                  int32_t* hyp_counts, uint64_t* hyp_costs);
+
+/* old/p3p.m:41-217 batched: world_pts n x 3 x 3 (row-major, point-major), bearings likewise;
+ * poses n x 4 x 12 ([C(3) R(9 row-major, cam->world)] per solution) */
+int vo_p3p_batch(vo_ctx* ctx, const double* world_pts, const double* bearings, int n, double* out_poses);
+
+/* ==== device-pointer entry points (inputs/outputs resident in HBM; asynchronous on the ctx
+ * stream).  Internal convention: image = nv rows of nu contiguous bytes, (u,v) zero-based;
+ * points structure-of-arrays. ==== */
+
+#define VO_NUM_FRAME_SLOTS 4
+/* build the float pyramid + Sobel gradients of a device image into a frame slot */
+int vo_dev_frame_build(vo_ctx* ctx, int slot, const uint8_t* d_img, int nu, int nv, int levels);
+/* track slot_a -> slot_b; wu/wv = window along u / v */
+int vo_dev_klt_track(vo_ctx* ctx, int slot_a, int slot_b, const double* d_pu, const double* d_pv, int n,
+                     int wu, int wv, int max_iters, double eps, double max_bidir_err, double* d_qu,
+                     double* d_qv, uint8_t* d_valid, float* d_score, float* d_fb_err);
+/* u_is_rows: 1 when the u axis is the image's row (y) axis (MATLAB layout) */
+int vo_dev_select_candidates(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is_rows,
+                             const float* d_eu, const float* d_ev, int n_exist, const vo_sel_opts* opts,
+                             float* d_out_u, float* d_out_v, int32_t* d_out_lin, double* d_out_metric,
+                             int32_t* d_out_count);
+/* row-major device arrays: xy C x 2, poses P x 12, X C x 3 */
+int vo_dev_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, const double* d_poses0,
+                       int P, const int32_t* d_pose_idx, int C, const double* d_pose1,
+                       const double* d_K, double* d_X, double* d_reproj, double* d_angle,
+                       uint8_t* d_valid);
+/* d_out: R_cw(9) t_cw(3) as doubles followed by vo_ransac_info as 5 int32 (pass >= 128 bytes) */
+int vo_dev_p3p_ransac(vo_ctx* ctx, const double* d_xy, const double* d_X, int M, const double* d_K,
+                      const vo_ransac_opts* opts, const int32_t* d_sample_idx, void* d_out,
+                      uint8_t* d_inliers);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

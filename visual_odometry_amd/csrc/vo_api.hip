@@ -1,0 +1,273 @@
+// vo_api.hip -- the C ABI of libvo_hip.so (include/vo_hip.h): context, host-pointer entry points
+// (marshal -> device -> launch -> copy back) and device-pointer entry points.
+#include "vo_common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+// scratch buffer purposes
+enum { SB_PU = 0, SB_PV, SB_QU, SB_QV, SB_VALID, SB_SCORE, SB_IMG, SB_A, SB_B, SB_C, SB_D, SB_E, SB_F, SB_G, SB_H, SB_I };
+
+const char* vo_strerror(int code) {
+    switch (code) {
+        case VO_OK: return "ok";
+        case VO_ERR_NO_DEVICE: return "no HIP device available (there is no CPU fallback)";
+        case VO_ERR_BAD_ARG: return "bad argument";
+        case VO_ERR_HIP: return "HIP runtime error";
+        case VO_ERR_OOM: return "out of device memory";
+        case VO_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown error";
+    }
+}
+int vo_version(void) { return 100; }
+
+int vo_buf_reserve(vo_ctx* ctx, vo_buf* b, size_t bytes) {
+    if (bytes <= b->cap) return VO_OK;
+    if (b->p) {
+        VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        VO_HIP_CHECK(ctx, hipFree(b->p));
+        b->p = nullptr; b->cap = 0;
+    }
+    size_t cap = std::max<size_t>(bytes + bytes / 4, 4096);
+    VO_HIP_CHECK(ctx, hipMalloc(&b->p, cap));
+    b->cap = cap;
+    return VO_OK;
+}
+
+int vo_ctx_create(int device, vo_ctx** out) {
+    if (!out) return VO_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VO_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return VO_ERR_BAD_ARG;
+    if (hipSetDevice(device) != hipSuccess) return VO_ERR_HIP;
+    vo_ctx* c = new (std::nothrow) vo_ctx();
+    if (!c) return VO_ERR_OOM;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        vo_ctx_destroy(c);
+        return VO_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return VO_OK;
+}
+
+void vo_ctx_destroy(vo_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& f : c->frames) {
+        if (f.I) (void)hipFree(f.I);
+        if (f.Gu) (void)hipFree(f.Gu);
+        if (f.Gv) (void)hipFree(f.Gv);
+        if (f.img) (void)hipFree(f.img);
+    }
+    for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int vo_ctx_set_stream(vo_ctx* ctx, void* s) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return VO_OK;
+}
+void* vo_ctx_get_stream(vo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int vo_ctx_sync(vo_ctx* ctx) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+const char* vo_ctx_last_error(vo_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
+
+int vo_ctx_read_counters(vo_ctx* ctx, uint64_t out[4], int reset) {
+    if (!ctx || !out) return VO_ERR_BAD_ARG;
+    VO_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->d_counters, 32, hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) VO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+    VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+int vo_timer_start(vo_ctx* ctx) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    VO_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return VO_OK;
+}
+int vo_timer_stop_ms(vo_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return VO_ERR_BAD_ARG;
+    VO_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    VO_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+    VO_HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return VO_OK;
+}
+
+// ---- frame slots ----
+static int frame_prepare(vo_ctx* ctx, vo_pyr* f, int nu, int nv, int levels) {
+    if (nu < 8 || nv < 8 || levels < 1 || levels > VO_MAX_LEVELS) { ctx->last_error = "frame: bad shape or level count"; return VO_ERR_BAD_ARG; }
+    long tot = 0;
+    int a = nu, b = nv;
+    for (int l = 0; l < levels; ++l) {
+        f->nus[l] = a; f->nvs[l] = b; f->offs[l] = tot;
+        tot += (long)a * b;
+        a = (a + 1) / 2; b = (b + 1) / 2;
+    }
+    if (f->nus[levels - 1] < 2 || f->nvs[levels - 1] < 2) { ctx->last_error = "frame: too many pyramid levels for this image"; return VO_ERR_BAD_ARG; }
+    if ((size_t)tot > f->cap) {
+        VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (f->I) (void)hipFree(f->I);
+        if (f->Gu) (void)hipFree(f->Gu);
+        if (f->Gv) (void)hipFree(f->Gv);
+        f->I = f->Gu = f->Gv = nullptr; f->cap = 0;
+        VO_HIP_CHECK(ctx, hipMalloc((void**)&f->I, tot * sizeof(float)));
+        VO_HIP_CHECK(ctx, hipMalloc((void**)&f->Gu, tot * sizeof(float)));
+        VO_HIP_CHECK(ctx, hipMalloc((void**)&f->Gv, tot * sizeof(float)));
+        f->cap = (size_t)tot;
+    }
+    f->nu = nu; f->nv = nv; f->levels = levels; f->total = tot;
+    return VO_OK;
+}
+
+int vo_dev_frame_build(vo_ctx* ctx, int slot, const uint8_t* d_img, int nu, int nv, int levels) {
+    if (!ctx || !d_img || slot < 0 || slot >= VO_NUM_FRAME_SLOTS) return VO_ERR_BAD_ARG;
+    vo_pyr* f = &ctx->frames[slot];
+    f->valid = false;
+    int rc = frame_prepare(ctx, f, nu, nv, levels);
+    if (rc) return rc;
+    rc = vo_launch_frame_build(ctx, f, d_img);
+    if (rc) return rc;
+    f->valid = true; f->key = 0; f->stamp = ++ctx->clock;
+    return VO_OK;
+}
+
+int vo_dev_klt_track(vo_ctx* ctx, int sa, int sb, const double* d_pu, const double* d_pv, int n, int wu, int wv,
+                     int max_iters, double eps, double max_bidir, double* d_qu, double* d_qv, uint8_t* d_valid,
+                     float* d_score, float* d_fb) {
+    if (!ctx || sa < 0 || sa >= VO_NUM_FRAME_SLOTS || sb < 0 || sb >= VO_NUM_FRAME_SLOTS) return VO_ERR_BAD_ARG;
+    if (n == 0) return VO_OK;
+    if (n < 0 || !d_pu || !d_pv || !d_qu || !d_qv || !d_valid || !d_score) return VO_ERR_BAD_ARG;
+    if (!ctx->frames[sa].valid || !ctx->frames[sb].valid) { ctx->last_error = "klt: frame slot not built"; return VO_ERR_BAD_ARG; }
+    if (eps <= 0) eps = 0.01;
+    return vo_launch_klt(ctx, &ctx->frames[sa], &ctx->frames[sb], d_pu, d_pv, n, wu, wv, max_iters, eps, max_bidir,
+                         d_qu, d_qv, d_valid, d_score, d_fb);
+}
+
+// content hash for the host-API pyramid cache (the reference calls track twice per frame on the
+// same image pair, modules/VisualOdometry.m:71,278, and re-uses curr as next frame's prev)
+static uint64_t hash_image(const uint8_t* p, size_t n, int nu, int nv, int levels) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)nu << 40) ^ ((uint64_t)nv << 16) ^ (uint64_t)levels;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        h = (h ^ w) * 0x100000001B3ull;
+        h ^= h >> 29;
+    }
+    for (; i < n; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
+    return h ? h : 1;
+}
+
+// returns the slot holding the pyramid of this host image (building it if needed)
+static int frame_from_host(vo_ctx* ctx, const uint8_t* img, int nu, int nv, int levels, int avoid_slot, int* slot_out) {
+    const size_t nbytes = (size_t)nu * nv;
+    const uint64_t key = hash_image(img, nbytes, nu, nv, levels);
+    int lru = -1;
+    for (int s = 0; s < VO_NUM_FRAME_SLOTS; ++s) {
+        vo_pyr* f = &ctx->frames[s];
+        if (f->valid && f->key == key && f->nu == nu && f->nv == nv && f->levels == levels) {
+            f->stamp = ++ctx->clock;
+            *slot_out = s;
+            return VO_OK;
+        }
+        if (s == avoid_slot) continue;
+        if (lru < 0 || !f->valid || (ctx->frames[lru].valid && f->stamp < ctx->frames[lru].stamp)) lru = s;
+    }
+    vo_pyr* f = &ctx->frames[lru];
+    f->valid = false;
+    if (nbytes > f->img_cap) {
+        VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (f->img) (void)hipFree(f->img);
+        f->img = nullptr; f->img_cap = 0;
+        VO_HIP_CHECK(ctx, hipMalloc((void**)&f->img, nbytes));
+        f->img_cap = nbytes;
+    }
+    VO_HIP_CHECK(ctx, hipMemcpyAsync(f->img, img, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    int rc = frame_prepare(ctx, f, nu, nv, levels);
+    if (rc) return rc;
+    rc = vo_launch_frame_build(ctx, f, f->img);
+    if (rc) return rc;
+    f->valid = true; f->key = key; f->stamp = ++ctx->clock;
+    *slot_out = lru;
+    return VO_OK;
+}
+
+template <typename T>
+static int dbuf(vo_ctx* ctx, int which, size_t count, T** out) {
+    int rc = vo_buf_reserve(ctx, &ctx->scratch[which], count * sizeof(T));
+    *out = (T*)ctx->scratch[which].p;
+    return rc;
+}
+
+int vo_klt_track(vo_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int H, int W, vo_layout lay,
+                 const void* pts_xy, int N, int pts_is_double, const vo_klt_opts* o, void* out_pts_xy,
+                 uint8_t* out_valid, void* out_scores) {
+    if (!ctx || !o) return VO_ERR_BAD_ARG;
+    if (N == 0) return VO_OK; // modules/KLTTracker.m:33-36: outputs stay the caller's typed empties
+    if (N < 0 || !img1 || !img2 || !pts_xy || !out_pts_xy || !out_valid || !out_scores || H <= 0 || W <= 0) return VO_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    const int nu = lay.col_major ? H : W, nv = lay.col_major ? W : H;
+    const int wu = lay.col_major ? o->block_h : o->block_w, wv = lay.col_major ? o->block_w : o->block_h;
+    int sa, sb, rc;
+    if ((rc = frame_from_host(ctx, img1, nu, nv, o->levels, -1, &sa))) return rc;
+    if ((rc = frame_from_host(ctx, img2, nu, nv, o->levels, sa, &sb))) return rc;
+    // marshal points to internal (u,v) zero-based SoA doubles
+    std::vector<double> h(2 * (size_t)N);
+    const double base = (double)lay.index_base;
+    for (int i = 0; i < N; ++i) {
+        double x, y;
+        const size_t ix = lay.col_major ? (size_t)i : 2 * (size_t)i, iy = lay.col_major ? (size_t)N + i : 2 * (size_t)i + 1;
+        if (pts_is_double) { x = ((const double*)pts_xy)[ix]; y = ((const double*)pts_xy)[iy]; }
+        else { x = ((const float*)pts_xy)[ix]; y = ((const float*)pts_xy)[iy]; }
+        x -= base; y -= base;
+        h[i] = lay.col_major ? y : x;
+        h[(size_t)N + i] = lay.col_major ? x : y;
+    }
+    double *d_p, *d_q; uint8_t* d_valid; float* d_score;
+    if ((rc = dbuf(ctx, SB_PU, 2 * (size_t)N, &d_p))) return rc;
+    if ((rc = dbuf(ctx, SB_QU, 2 * (size_t)N, &d_q))) return rc;
+    if ((rc = dbuf(ctx, SB_VALID, (size_t)N, &d_valid))) return rc;
+    if ((rc = dbuf(ctx, SB_SCORE, (size_t)N, &d_score))) return rc;
+    VO_HIP_CHECK(ctx, hipMemcpyAsync(d_p, h.data(), 2 * (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const double eps = o->eps > 0 ? o->eps : 0.01;
+    rc = vo_launch_klt(ctx, &ctx->frames[sa], &ctx->frames[sb], d_p, d_p + N, N, wu, wv, o->max_iters, eps,
+                       o->max_bidir_err, d_q, d_q + N, d_valid, d_score, nullptr);
+    if (rc) return rc;
+    std::vector<float> hs((size_t)N);
+    VO_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), d_q, 2 * (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(ctx, hipMemcpyAsync(out_valid, d_valid, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(ctx, hipMemcpyAsync(hs.data(), d_score, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < N; ++i) {
+        const double u = h[i] + base, v = h[(size_t)N + i] + base;
+        const double x = lay.col_major ? v : u, y = lay.col_major ? u : v;
+        const size_t ix = lay.col_major ? (size_t)i : 2 * (size_t)i, iy = lay.col_major ? (size_t)N + i : 2 * (size_t)i + 1;
+        if (pts_is_double) {
+            ((double*)out_pts_xy)[ix] = x; ((double*)out_pts_xy)[iy] = y;
+            ((double*)out_scores)[i] = (double)hs[i];
+        } else {
+            ((float*)out_pts_xy)[ix] = (float)x; ((float*)out_pts_xy)[iy] = (float)y;
+            ((float*)out_scores)[i] = hs[i];
+        }
+    }
+    return VO_OK;
+}
+
+#include "vo_api_rest.inc"

@@ -1,0 +1,91 @@
+// vo_common.h -- internal declarations shared by the HIP translation units of libvo_hip.so.
+// Each .hip file holds its kernels and the host launchers for them; vo_api.hip is the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/vo_hip.h"
+
+#define VO_MAX_LEVELS 8
+#define VO_MIN_EIG 1e-3f
+
+struct vo_pyr {            // one frame slot: float pyramid + Sobel/8 gradients, all levels contiguous
+    bool valid = false;
+    uint64_t key = 0;      // host-side content hash (host API cache)
+    uint64_t stamp = 0;    // LRU
+    int nu = 0, nv = 0, levels = 0;
+    int nus[VO_MAX_LEVELS], nvs[VO_MAX_LEVELS];
+    long offs[VO_MAX_LEVELS];
+    long total = 0;
+    float* I = nullptr;    // total floats
+    float* Gu = nullptr;
+    float* Gv = nullptr;
+    size_t cap = 0;        // floats allocated per plane
+    uint8_t* img = nullptr; // device copy of the uint8 image (host API)
+    size_t img_cap = 0;
+};
+
+struct vo_buf {            // grow-only device buffer
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct vo_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    vo_pyr frames[VO_NUM_FRAME_SLOTS];
+    uint64_t clock = 0;
+    unsigned long long* d_counters = nullptr; // 4 x u64
+    vo_buf scratch[16];                        // purpose-indexed scratch (see vo_api.hip)
+    std::string last_error;
+};
+
+#define VO_HIP_CHECK(ctx, expr)                                                        \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e__);    \
+            return e__ == hipErrorOutOfMemory ? VO_ERR_OOM : VO_ERR_HIP;               \
+        }                                                                              \
+    } while (0)
+
+int vo_buf_reserve(vo_ctx* ctx, vo_buf* b, size_t bytes);
+
+// ---- launchers (each returns VO_OK or an error code; all asynchronous on ctx->stream) ----
+int vo_launch_frame_build(vo_ctx* ctx, vo_pyr* f, const uint8_t* d_img);
+int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d_pu, const double* d_pv, int n,
+                  int wu, int wv, int max_iters, double eps, double max_bidir, double* d_qu, double* d_qv,
+                  uint8_t* d_valid, float* d_score, float* d_fb);
+
+struct vo_sel_work {       // device scratch of the selection pipeline
+    double* resp; unsigned long long* maxbits; int32_t* blk_counts; int32_t* blk_offs;
+    int32_t* lin; float* lu; float* lv; double* metric; uint8_t* keep; uint8_t* sel;
+    int32_t* m0; unsigned long long* cell_key; int32_t* cell_idx; int cap; int nblk;
+};
+int vo_launch_response(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int scorer, int fs, double kappa,
+                       double* d_resp, unsigned long long* d_maxbits);
+int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is_rows, const float* d_eu,
+                     const float* d_ev, int n_exist, const vo_sel_opts* o, vo_sel_work* w, float* d_out_u,
+                     float* d_out_v, int32_t* d_out_lin, double* d_out_metric, int32_t* d_out_count);
+int vo_launch_greedy(vo_ctx* ctx, double* d_scores_work, int nu, int nv, int num, int r, int32_t* d_out_uv,
+                     unsigned long long* d_tmp);
+
+struct vo_strides { long xi, xc; }; // element (i, c) at base[i*xi + c*xc]
+int vo_launch_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, vo_strides sxy,
+                          const double* d_poses0, int pose_col_major, const int32_t* d_pose_idx, int C,
+                          const double* d_pose1, const double* d_K, double* d_X, vo_strides sX,
+                          double* d_reproj, double* d_angle, uint8_t* d_valid);
+int vo_launch_angle(vo_ctx* ctx, const double* d_X, vo_strides sX, int n, const double* d_pose0,
+                    const double* d_pose1, int pose_col_major, double* d_angle);
+int vo_launch_in_front(vo_ctx* ctx, const double* d_cam, int cam_col_major, const double* d_X, vo_strides sX,
+                       int n, uint8_t* d_valid);
+int vo_launch_reproj(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int n,
+                     const double* d_pose, int pose_col_major, const double* d_K, double* d_err);
+
+struct vo_ransac_work { double* Rt; int32_t* cnt; unsigned long long* cost; };
+int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int M,
+                     const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
+                     vo_ransac_work* w, void* d_out, uint8_t* d_inliers);
+int vo_launch_p3p_batch(vo_ctx* ctx, const double* d_P, const double* d_f, int n, double* d_poses);

@@ -1,0 +1,142 @@
+"""Seeded synthetic inputs of the shapes SURVEY.md section 8(d) names (no dataset ships with the
+reference: data/.gitkeep only).  Pure numpy/scipy, host side; used by bench.py and the tests.
+
+Images are returned as numpy uint8 arrays in memory order [v][u] (see include/vo_hip.h); for a
+"numpy" image that is [y][x]; a MATLAB column-major H x W image is the same bytes seen as [x][y].
+"""
+import numpy as np
+from scipy import ndimage
+
+KITTI_K = np.array([[7.188560000000e+02, 0, 6.071928000000e+02],
+                    [0, 7.188560000000e+02, 1.852157000000e+02],
+                    [0, 0, 1]])  # utils/dataLoaderKitti.m:50-52
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.Philox(seed))
+
+
+def texture(nv, nu, seed=1023, sigma=2.0, margin=32):
+    """Band-limited texture (float64, range [16,240]) with a margin for warping."""
+    r = _rng(seed)
+    t = r.integers(0, 256, size=(nv + 2 * margin, nu + 2 * margin)).astype(np.float64)
+    t = ndimage.gaussian_filter(t, sigma, mode="wrap")
+    t = (t - t.min()) / (t.max() - t.min())
+    return 16.0 + 224.0 * t
+
+
+def frame_pair(nv=376, nu=1241, seed=1023, shift=(3.3, -2.6), zoom=0.0, noise=0.0, margin=32):
+    """Two uint8 frames: frame2(p + shift + zoom*(p-c)) = frame1(p).  Returns img1, img2 and a
+    function mapping frame-1 (u,v) to the true frame-2 position."""
+    tex = texture(nv, nu, seed, margin=margin)
+    vv, uu = np.mgrid[0:nv, 0:nu].astype(np.float64)
+    img1 = ndimage.map_coordinates(tex, [vv + margin, uu + margin], order=3, mode="nearest")
+    cu, cv = (nu - 1) / 2.0, (nv - 1) / 2.0
+    s = 1.0 + zoom
+    # q = c + s (p - c) + shift  =>  p = c + (q - c - shift)/s
+    pu = cu + (uu - cu - shift[0]) / s
+    pv = cv + (vv - cv - shift[1]) / s
+    img2 = ndimage.map_coordinates(tex, [pv + margin, pu + margin], order=3, mode="nearest")
+    if noise > 0:
+        r = _rng(seed + 7)
+        img1 = img1 + r.normal(0, noise, img1.shape)
+        img2 = img2 + r.normal(0, noise, img2.shape)
+    img1 = np.clip(np.rint(img1), 0, 255).astype(np.uint8)
+    img2 = np.clip(np.rint(img2), 0, 255).astype(np.uint8)
+
+    def truth(u, v):
+        return cu + s * (np.asarray(u) - cu) + shift[0], cv + s * (np.asarray(v) - cv) + shift[1]
+
+    return img1, img2, truth
+
+
+def frame_sequence(n_frames, nv=376, nu=1241, seed=1023, max_shift=6.0, zoom=0.005, noise=1.0):
+    """frame k+1 = frame k warped by U[-6,6]^2 px + 0.5 % zoom + N(0,1) noise.  Each
+    frame is resampled from the base texture with the accumulated warp (margin sized for it)."""
+    r = _rng(seed + 1)
+    margin = int(np.ceil(n_frames * (max_shift + zoom * max(nu, nv)))) + 8
+    tex = texture(nv, nu, seed, margin=margin)
+    vv, uu = np.mgrid[0:nv, 0:nu].astype(np.float64)
+    cu, cv = (nu - 1) / 2.0, (nv - 1) / 2.0
+    frames, warps = [], []
+    S, tu, tv = 1.0, 0.0, 0.0  # q = c + S (p - c) + t  maps frame-0 coords to frame-k coords
+    for k in range(n_frames):
+        pu = cu + (uu - cu - tu) / S
+        pv = cv + (vv - cv - tv) / S
+        img = ndimage.map_coordinates(tex, [pv + margin, pu + margin], order=3, mode="nearest")
+        if noise > 0:
+            img = img + _rng(seed + 100 + k).normal(0, noise, img.shape)
+        frames.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+        warps.append((S, tu, tv))
+        du, dv = r.uniform(-max_shift, max_shift, 2)
+        S, tu, tv = S * (1 + zoom), (1 + zoom) * tu + du, (1 + zoom) * tv + dv
+    return frames, warps
+
+
+def keypoints(n, nv=376, nu=1241, seed=2047, border=20.5):
+    """(u,v) ~ U[border, n-1-border], float32-representable (41x41 windows interior)."""
+    r = _rng(seed)
+    u = r.uniform(border, nu - 1 - border, n).astype(np.float32).astype(np.float64)
+    v = r.uniform(border, nv - 1 - border, n).astype(np.float32).astype(np.float64)
+    return u, v
+
+
+def rot_y(deg):
+    a = np.deg2rad(deg)
+    return np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+
+
+def pose43(R_cw, C):
+    """MATLAB pose [R_WC; t_WC] (modules/VisualOdometry.m:318): orientation = R_cw, location = C."""
+    return np.vstack([R_cw, np.asarray(C, dtype=np.float64).reshape(1, 3)])
+
+
+def project(K, R_cw, C, X):
+    xc = (X - C) @ R_cw.T
+    uvw = xc @ K.T
+    return uvw[:, :2] / uvw[:, 2:3], xc[:, 2]
+
+
+def pnp_scene(n, seed=4095, K=KITTI_K, nv=376, nu=1241, noise=0.3, outlier_frac=0.2):
+    """landmarks back-projected from image points at Z~U[5,100] under the identity
+    pose; true pose = 0.8 m forward + 1 deg yaw; observations = projections + N(0,noise) px with a
+    fraction replaced by uniform gross outliers.  Image points use the K convention (x,y)."""
+    r = _rng(seed)
+    x = r.uniform(20, nu - 20, n); y = r.uniform(20, nv - 20, n)
+    Z = r.uniform(5, 100, n)
+    X = np.stack([(x - K[0, 2]) / K[0, 0] * Z, (y - K[1, 2]) / K[1, 1] * Z, Z], 1)
+    R_cw = rot_y(1.0)
+    C = np.array([0.0, 0.0, 0.8])
+    xy, depth = project(K, R_cw, C, X)
+    xy = xy + r.normal(0, noise, xy.shape)
+    n_out = int(round(outlier_frac * n))
+    out_idx = r.permutation(n)[:n_out]
+    xy[out_idx, 0] = r.uniform(0, nu, n_out)
+    xy[out_idx, 1] = r.uniform(0, nv, n_out)
+    is_out = np.zeros(n, bool); is_out[out_idx] = True
+    return xy, X, R_cw, C, is_out
+
+
+def triangulation_scene(n, seed=8191, K=KITTI_K, nv=376, nu=1241, noise=0.2, n_poses=10, step=0.8):
+    """C = n candidates whose first observations come from `n_poses` poses along a
+    straight track (temporal recall 10, modules/VisualOdometry.m:23)."""
+    r = _rng(seed)
+    x = r.uniform(20, nu - 20, n); y = r.uniform(20, nv - 20, n)
+    Z = r.uniform(5, 100, n)
+    # landmarks defined in the CURRENT camera frame (pose1), then moved to world
+    R1 = rot_y(2.0); C1 = np.array([0.3, 0.0, step * n_poses])
+    Xc = np.stack([(x - K[0, 2]) / K[0, 0] * Z, (y - K[1, 2]) / K[1, 1] * Z, Z], 1)
+    X = Xc @ R1 + C1
+    pose1 = pose43(R1, C1)
+    which = r.integers(0, n_poses, n)
+    poses0 = np.zeros((n, 4, 3)); xy0 = np.zeros((n, 2))
+    for k in range(n_poses):
+        Rk = rot_y(0.2 * k); Ck = np.array([0.02 * k, 0.0, step * k])
+        sel = which == k
+        poses0[sel] = pose43(Rk, Ck)
+        p, _ = project(K, Rk, Ck, X[sel])
+        xy0[sel] = p
+    xy1, _ = project(K, R1, C1, X)
+    xy0 = xy0 + r.normal(0, noise, xy0.shape)
+    xy1 = xy1 + r.normal(0, noise, xy1.shape)
+    return xy0, xy1, poses0, pose1, X
