@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tracked keypoints/s (+ VO frames/s) on KITTI-shaped synthetic frames.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--keypoints 50000] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = the hot path of one VO frame with every input resident in HBM (visual_odometry_amd/
+device.py): pyramid build, KLT track of the landmark and candidate keypoints, P3P-RANSAC pose,
+batched triangulation, candidate selection.  Default workload = BASELINE.json configs[3] (synthetic
+1241x376, 50k keypoints per frame split into 25k landmarks + 25k candidates, 4 levels, 2k RANSAC
+hypotheses) -- the configuration the north-star target is quoted on.  N > 1: every rank runs its own
+seed-offset sequence (weak scaling, no data-path collective); RCCL gathers the statistics once.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WINDOW_PX = 41 * 41
+FLOP_SETUP_PX, FLOP_ITER_PX = 24, 11      # algorithmic flops per window pixel
+FP32_PEAK_TFLOPS = 157.3                  # MI355X_MICROARCH.md: fp32 vector peak = fp32-input MFMA peak
+
+
+def cpu_baseline(args, frames):
+    """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload: one
+    frame's two KLT tracks on a subset of the keypoints plus RANSAC / triangulation / selection at
+    reduced size, scaled to keypoints/s of a whole frame."""
+    import numpy as np
+    from oracle import oracle
+    from visual_odometry_amd import synth
+    threads = min(16, os.cpu_count() or 1)
+    n = min(args.keypoints, 4000)
+    pu, pv = synth.keypoints(n)
+    t0 = time.perf_counter()
+    oracle.klt_track(frames[0], frames[1], pu, pv, threads=threads)
+    t_klt = time.perf_counter() - t0
+    m = min(args.keypoints // 2, 5000); h = 200
+    xy, X, *_ = synth.pnp_scene(m)
+    t0 = time.perf_counter()
+    oracle.p3p_ransac(xy, X, synth.KITTI_K, num_hyp=h, mode=1, min_inliers=4, threads=threads)
+    t_rs = (time.perf_counter() - t0) * (args.hyp / h) * ((args.keypoints // 2) / m)
+    xy0, xy1, poses0, pose1, _ = synth.triangulation_scene(m)
+    t0 = time.perf_counter()
+    oracle.triangulate(xy0, xy1, poses0, pose1, synth.KITTI_K)
+    t_tr = (time.perf_counter() - t0) * ((args.keypoints // 2) / m)
+    eu, ev = synth.keypoints(min(args.keypoints, 2000))
+    t0 = time.perf_counter()
+    oracle.select_candidates(frames[1], eu.astype("float32"), ev.astype("float32"), keep=100)
+    t_sel = (time.perf_counter() - t0)  # the all-pairs distance test scales with N_exist: a lower bound
+    t_frame = t_klt * (args.keypoints / n) + t_rs + t_tr + t_sel
+    return {"value": args.keypoints / t_frame, "unit": "keypoints/s", "cores": threads, "kind": "port",
+            "frames_per_s": 1.0 / t_frame,
+            "sample": f"oracle (C, -O2, OpenMP {threads} threads): KLT on {n} of {args.keypoints} keypoints of one "
+                      f"1241x376 frame pair ({t_klt:.2f} s), RANSAC {h} hyp x {m} pts, triangulation {m}, selection vs "
+                      f"{len(eu)} points; scaled linearly to one full frame"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--keypoints", type=int, default=50000, help="keypoints tracked per frame (landmarks + candidates)")
+    ap.add_argument("--hyp", type=int, default=2000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    from visual_odometry_amd import _lib, dist
+    from visual_odometry_amd.device import FrameWorkload
+
+    rank, local_rank, world = dist.init()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no HIP device (there is no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    ctx = _lib.Context(local_rank)
+    nl = args.keypoints // 2
+    nc = args.keypoints - nl
+    wl = FrameWorkload(ctx, nl, nc, num_hyp=args.hyp, seed=1023 + 7919 * rank)
+
+    for _ in range(args.warmup):
+        wl.step()
+    wl.sync(); torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    wl.sync(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dist.barrier()
+    valid = int(wl.vl.sum().item()) + int(wl.vc.sum().item())
+    inl = int(wl.rs_inl.sum().item())
+    stats = dist.gather_stats({"frames": args.steps, "keypoints_tracked": args.steps * args.keypoints,
+                               "keypoints_valid": valid, "ransac_inliers": inl, "elapsed_s": elapsed})
+
+    # ---- dominant kernel: k_lk.  HIP events on the ctx stream around back-to-back launches of the
+    # landmark track; algorithmic flops from the executed iteration / set-up counters.
+    roof = None
+    stage_ms = {}
+    if rank == 0:
+        a, b = wl.k % 2, (wl.k + 1) % 2
+        wl.build(b, (wl.k % wl.n_frames) + 1)
+        reps = 20
+        wl.track_landmarks(a, b); wl.sync()
+        ctx.counters(reset=True)
+        ctx.timer_start()
+        for _ in range(reps):
+            wl.track_landmarks(a, b)
+        ms = ctx.timer_stop_ms() / reps
+        it, kp, su, _ = ctx.counters(reset=True)
+        flops = WINDOW_PX * (FLOP_ITER_PX * it + FLOP_SETUP_PX * su) / reps
+        ach = flops / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
+                "traffic": None, "kernel": "k_lk<41x41>", "launch_ms": ms, "keypoints_per_launch": nl,
+                "iters_per_keypoint": it / max(kp, 1), "setups_per_keypoint": su / max(kp, 1),
+                "note": "fp32 VALU-bound kernel, no MFMA used (nothing here is a dense contraction); peak = fp32 "
+                        "vector rate = fp32-input MFMA rate; flops = 1681 px x (11/iteration + 24/set-up), SURVEY 8d"}
+        for name, fn in (("pyramid", lambda: wl.build(b, (wl.k % wl.n_frames) + 1)), ("klt_landmarks", lambda: wl.track_landmarks(a, b)),
+                         ("klt_candidates", lambda: wl.track_candidates(a, b)), ("ransac", wl.pose),
+                         ("triangulate", wl.triangulate), ("select", lambda: wl.select(1))):
+            fn(); wl.sync()
+            ctx.timer_start()
+            for _ in range(5):
+                fn()
+            stage_ms[name] = ctx.timer_stop_ms() / 5
+
+    if rank == 0:
+        value = stats["keypoints_tracked"] / stats["elapsed_s"]
+        line = {"metric": "tracked_keypoints_per_s", "value": value, "unit": "keypoints/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * stats["elapsed_s"] / args.steps,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "frames_per_s": stats["frames"] / stats["elapsed_s"],
+                "config": {"workload": "BASELINE configs[3]: synthetic 1241x376 frames, 16-frame loop per GPU, "
+                                       f"{args.keypoints} keypoints/frame ({nl} landmarks + {nc} candidates), 4-level pyramid, "
+                                       f"41x41 window, <=50 iterations, fwd-bwd 2 px, {args.hyp} P3P-RANSAC hypotheses (MSAC) on the "
+                                       "landmarks, batched triangulation of the candidates, min-eigen selection (keep 100)",
+                           "keypoints_per_frame": args.keypoints, "hypotheses": args.hyp,
+                           "parallelism": f"{world} independent sequence(s), one per GPU"},
+                "valid_fraction": stats["keypoints_valid"] / (world * args.keypoints),
+                "stage_ms": stage_ms, "roofline": roof}
+        if not args.no_cpu:
+            frames = [wl.frames[0].cpu().numpy(), wl.frames[1].cpu().numpy()]
+            line["cpu_baseline"] = cpu_baseline(args, frames)
+        print(json.dumps(line))
+    dist.barrier()
+    dist.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,7 +138,8 @@ int vo_select_keypoints_greedy(vo_ctx* ctx, const double* scores, int H, int W, 
                                int r, int32_t* out_rc);
 
 /* modules/VisualOdometry.m:87-113 batched: first_xy / curr_xy C x 2, first_poses P x (4x3),
- * first_pose_idx (optional, C entries into the pose table; NULL: P == C, identity),
+ * first_pose_idx (optional, C entries into the pose table counted from lay.index_base; NULL: P == C,
+ * candidate i uses pose i),
  * curr_pose 4x3, K.  Outputs: out_X C x 3, out_reproj C (mean over the two views),
  * out_angle_deg C (calculateAngleDeg), out_valid C (positive depth in both views). */
 int vo_triangulate_candidates(vo_ctx* ctx, vo_layout lay, const double* first_xy, const double* curr_xy,
@@ -158,12 +159,15 @@ int vo_reproj_error(vo_ctx* ctx, vo_layout lay, const double* keypoints_xy, cons
 
 /* modules/VisualOdometry.m:285-289 / old/ransacLocalization.m.  img_pts M x 2, world_pts M x 3.
  * sample_idx (optional): num_hyp x 3 zero-based indices, row-major, overriding the seeded stream.
+ * hyp_poses_in (optional): num_hyp x 4 x 12 doubles [R_cw(9, row-major) t_cw(3)] scored INSTEAD of
+ * generating hypotheses -- the "identical hypotheses" hook of the parity contract.
  * Outputs: R_wc (3x3 world orientation, in the chosen layout), t_wc (world location) -- i.e.
- * pose = [R_wc; t_wc]; inliers M; info.  hyp_counts / hyp_costs (optional, num_hyp x 4). */
+ * pose = [R_wc; t_wc]; inliers M; info.  Optional: hyp_counts / hyp_costs (num_hyp x 4),
+ * hyp_poses_out (num_hyp x 4 x 12, the hypotheses that were scored). */
 int vo_p3p_ransac(vo_ctx* ctx, vo_layout lay, const double* img_pts, const double* world_pts, int M,
                   const double* K, const vo_ransac_opts* opts, const int32_t* sample_idx,
-                  double* out_R_wc, double* out_t_wc, uint8_t* out_inliers, vo_ransac_info* info,
-                  int32_t* hyp_counts, uint64_t* hyp_costs);
+                  const double* hyp_poses_in, double* out_R_wc, double* out_t_wc, uint8_t* out_inliers,
+                  vo_ransac_info* info, int32_t* hyp_counts, uint64_t* hyp_costs, double* hyp_poses_out);
 
 /* old/p3p.m:41-217 batched: world_pts n x 3 x 3 (row-major, point-major), bearings likewise;
  * poses n x 4 x 12 ([C(3) R(9 row-major, cam->world)] per solution) */
@@ -192,8 +196,8 @@ int vo_dev_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, co
                        uint8_t* d_valid);
 /* d_out: R_cw(9) t_cw(3) as doubles followed by vo_ransac_info as 5 int32 (pass >= 128 bytes) */
 int vo_dev_p3p_ransac(vo_ctx* ctx, const double* d_xy, const double* d_X, int M, const double* d_K,
-                      const vo_ransac_opts* opts, const int32_t* d_sample_idx, void* d_out,
-                      uint8_t* d_inliers);
+                      const vo_ransac_opts* opts, const int32_t* d_sample_idx,
+                      const double* d_hyp_poses_in, void* d_out, uint8_t* d_inliers);
 
 #ifdef __cplusplus
 }

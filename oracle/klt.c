@@ -52,7 +52,7 @@ void vo_or_build_pyramid(const uint8_t* img, int nu, int nv, int levels, double*
     for (int l = 1; l < levels; ++l) pyr_down(pyr + offs[l - 1], nus[l - 1], nvs[l - 1], pyr + offs[l]);
 }
 
-/* N2 */
+/* N2 (Sobel/8 of a whole plane; the tracker applies the same operator to the sampled template) */
 void vo_or_gradients(const double* I, int nu, int nv, double* gu, double* gv) {
     for (int v = 0; v < nv; ++v) {
         int vm = clampi(v - 1, 0, nv - 1), vp = clampi(v + 1, 0, nv - 1);
@@ -83,24 +83,20 @@ static inline double bilin(const double* I, int nu, int nv, double u, double v) 
 typedef struct {
     int levels, nus[VO_MAX_LEVELS], nvs[VO_MAX_LEVELS];
     long offs[VO_MAX_LEVELS];
-    double *I, *gu, *gv;
+    double* I;
 } pyr_t;
 
 static void pyr_make(pyr_t* p, const uint8_t* img, int nu, int nv, int levels) {
     p->levels = levels;
     long tot = vo_or_pyramid_layout(nu, nv, levels, p->nus, p->nvs, p->offs);
     p->I = (double*)malloc(sizeof(double) * tot);
-    p->gu = (double*)malloc(sizeof(double) * tot);
-    p->gv = (double*)malloc(sizeof(double) * tot);
     vo_or_build_pyramid(img, nu, nv, levels, p->I);
-    for (int l = 0; l < levels; ++l)
-        vo_or_gradients(p->I + p->offs[l], p->nus[l], p->nvs[l], p->gu + p->offs[l], p->gv + p->offs[l]);
 }
-static void pyr_free(pyr_t* p) { free(p->I); free(p->gu); free(p->gv); }
+static void pyr_free(pyr_t* p) { free(p->I); }
 
 /* N4: one direction A -> B.  returns flags: bit0 lost, bit1 flat at level 0 */
 static int lk_one(const pyr_t* A, const pyr_t* B, double pu, double pv, const vo_or_klt_opts* o,
-                  double* T, double* Tu, double* Tv, double* qu, double* qv, double* ssd_out,
+                  double* T, double* Tu, double* Tv, double* E, double* qu, double* qv, double* ssd_out,
                   int* iters) {
     const int L = o->levels, wu = o->wu, wv = o->wv, npx = wu * wv;
     const int ru = (wu - 1) / 2, rv = (wv - 1) / 2;
@@ -111,18 +107,22 @@ static int lk_one(const pyr_t* A, const pyr_t* B, double pu, double pv, const vo
         const double s = (double)(1 << l);
         const int nu = A->nus[l], nv = A->nvs[l];
         const double* AI = A->I + A->offs[l];
-        const double* Agu = A->gu + A->offs[l];
-        const double* Agv = A->gv + A->offs[l];
         const double* BI = B->I + B->offs[l];
         const double plu = pu / s, plv = pv / s;
         double Guu = 0, Guv = 0, Gvv = 0;
+        /* N4: template sampled on the window grown by one pixel; gradients = Sobel/8 of the samples */
+        const int ew = wu + 2;
+        for (int j = 0; j < wv + 2; ++j)
+            for (int i = 0; i < ew; ++i)
+                E[j * ew + i] = bilin(AI, nu, nv, plu + (double)(i - ru - 1), plv + (double)(j - rv - 1));
         for (int j = 0; j < wv; ++j)
             for (int i = 0; i < wu; ++i) {
-                double su = plu + (double)(i - ru), sv = plv + (double)(j - rv);
                 int k = j * wu + i;
-                T[k] = bilin(AI, nu, nv, su, sv);
-                Tu[k] = bilin(Agu, nu, nv, su, sv);
-                Tv[k] = bilin(Agv, nu, nv, su, sv);
+#define EE(a, b) E[(j + (b)) * ew + (i + (a))]
+                T[k] = EE(1, 1);
+                Tu[k] = ((EE(2, 0) - EE(0, 0)) + 2.0 * (EE(2, 1) - EE(0, 1)) + (EE(2, 2) - EE(0, 2))) * 0.125;
+                Tv[k] = ((EE(0, 2) - EE(0, 0)) + 2.0 * (EE(1, 2) - EE(1, 0)) + (EE(2, 2) - EE(2, 0))) * 0.125;
+#undef EE
                 Guu += Tu[k] * Tu[k]; Guv += Tu[k] * Tv[k]; Gvv += Tv[k] * Tv[k];
             }
         const double dif = Guu - Gvv;
@@ -190,17 +190,17 @@ int vo_or_klt_track(const uint8_t* img1, const uint8_t* img2, int nu, int nv, co
     (void)nth;
 #pragma omp parallel num_threads(nth)
     {
-        double* T = (double*)malloc(sizeof(double) * 3 * npx);
-        double *Tu = T + npx, *Tv = T + 2 * npx;
+        double* T = (double*)malloc(sizeof(double) * (3 * npx + (o->wu + 2) * (o->wv + 2)));
+        double *Tu = T + npx, *Tv = T + 2 * npx, *E = T + 3 * npx;
 #pragma omp for schedule(dynamic, 16)
         for (int i = 0; i < n; ++i) {
             double fu, fv, ssd, bu = 0, bv = 0, ssd2;
             int it = 0;
-            int fl = lk_one(&A, &B, pu[i], pv[i], o, T, Tu, Tv, &fu, &fv, &ssd, &it);
+            int fl = lk_one(&A, &B, pu[i], pv[i], o, T, Tu, Tv, E, &fu, &fv, &ssd, &it);
             int ok = (fl == 0);
             double fb = NAN;
             if (!(fl & 1) && o->max_bidir >= 0) {
-                int fl2 = lk_one(&B, &A, fu, fv, o, T, Tu, Tv, &bu, &bv, &ssd2, &it);
+                int fl2 = lk_one(&B, &A, fu, fv, o, T, Tu, Tv, E, &bu, &bv, &ssd2, &it);
                 if (fl2 & 1) ok = 0;
                 else {
                     double eu = pu[i] - bu, ev = pv[i] - bv;

@@ -15,8 +15,8 @@
  *  - best of the 4 solutions: strict >, ties keep earlier (:86-99).
  *  - best-so-far update strict > and >= min_inliers (:107-111) [mode 0]; strict < on cost [mode 1].
  *  - adaptive stop (:113-124) with the option values instead of the hard-coded 0.95 / 15000:
- *    or = min(0.9, 1 - best/m); N = min(num_hyp, log(1-conf)/log(1-(1-or)^3)); stop once the
- *    number of consumed hypotheses >= N.
+ *    or = min(0.9, 1 - best/m); N = log(1-conf)/log(1-(1-or)^3); after `used` hypotheses the
+ *    loop goes on only while N > used + 1 (:44, `while num_iterations > i`) and used < num_hyp.
  *  - the result is the best hypothesis' pose (no DLT refit: estimatePoseDLT is not in the repo,
  *    ransacLocalization.m:136-140).
  *  - complex principal cube root (solveQuartic.m:51,54): |z|^(1/3) (cos(arg/3) + i sin(arg/3)).
@@ -304,9 +304,8 @@ int vo_or_p3p_ransac(const double* xy, const double* X, int m, const double* K, 
             double orat = 1.0 - (double)bcnt / (double)m;
             if (orat > 0.9) orat = 0.9;
             double wi = 1.0 - orat;
-            double Nn = log(1.0 - o->confidence) / log(1.0 - wi * wi * wi);
-            N = Nn < (double)H ? Nn : (double)H;
-            if ((double)used >= N) break;
+            N = log(1.0 - o->confidence) / log(1.0 - wi * wi * wi);   /* :121 */
+            if (!(N > (double)(used + 1))) break;                        /* :44 `while num_iterations > i`, i = used + 1 */
         }
     }
     if (trials_used) *trials_used = used;

@@ -32,8 +32,9 @@
  * N2 gradients   Sobel/8, replicate border: gu = ([1 2 1]^T along v) x ([-1 0 1] along u) / 8.
  * N3 bilinear    sample(I,u,v): iu=floor(u), fu=u-iu, taps clamp(iu), clamp(iu+1) (replicate).
  * N4 LK          per point, coarse->fine, forward-additive with fixed template gradient
- *                (Bouguet 2001): template T,Tu,Tv = bilinear samples of image A (I, gu, gv) on the
- *                wu x wv window centred at p/2^l; G = sum [Tu^2 TuTv; TuTv Tv^2];
+ *                (Bouguet 2001): E = bilinear samples of image A on the (wu+2) x (wv+2) window
+ *                centred at p/2^l; template T = interior of E; Tu,Tv = Sobel/8 (N2 operator) of E,
+ *                i.e. the gradient of the sub-pixel-sampled patch; G = sum [Tu^2 TuTv; TuTv Tv^2];
  *                level is "flat" if mineig(G)/npx < VO_MIN_EIG (then no update at that level; at
  *                level 0 the point is invalid).  Iterate k < max_iters: J = samples of image B at
  *                p/2^l + g + d; b = sum (T-J)[Tu Tv]; delta = G^-1 b; d += delta; stop when

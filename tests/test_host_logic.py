@@ -1,0 +1,110 @@
+"""Host-side logic of the MATLAB-signature mirror (visual_odometry_amd/modules.py) on CPU: the
+order-dependent merge policies of candidateTriangulation with the device calls replaced by the oracle
+(monkeypatched), so that the policy code is exercised without a GPU."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from visual_odometry_amd import modules, ops, synth
+
+K = synth.KITTI_K
+
+
+class FakeTracker:
+    """track() returns scripted results (positions unchanged, chosen validity)."""
+
+    def __init__(self, valid):
+        self.valid = np.asarray(valid, bool)
+
+    def track(self, img1, img2, pts):
+        pts = np.asarray(pts, np.float64).reshape(-1, 2)
+        if len(pts) == 0:
+            return np.empty((0, 2)), np.empty((0,), bool), np.empty((0,))
+        return pts.copy(), self.valid[:len(pts)].copy(), np.ones(len(pts))
+
+
+@pytest.fixture
+def oracle_geometry(monkeypatch):
+    def tri(first_xy, curr_xy, first_poses, curr_pose, Kc, **kw):
+        return oracle.triangulate(first_xy, curr_xy, np.asarray(first_poses).reshape(-1, 12), curr_pose, Kc)
+    monkeypatch.setattr(ops, "triangulate_candidates", tri)
+
+
+def scripted_state(n_cand=6, n_land=3):
+    """Candidates 0..n-1 first seen from the origin pose; current pose 1 m to the right.  Near
+    points (Z = 4) subtend a large angle, far ones (Z = 400) a tiny one."""
+    pose0 = synth.pose43(np.eye(3), [0, 0, 0]); pose1 = synth.pose43(np.eye(3), [1.0, 0, 0])
+    Z = np.array([4.0, 400.0, 4.0, 400.0, 4.0, 4.0])[:n_cand]
+    X = np.stack([np.linspace(-1, 1, n_cand), np.zeros(n_cand), Z], 1)
+    xy0, _ = synth.project(K, np.eye(3), np.zeros(3), X)
+    xy1, _ = synth.project(K, np.eye(3), np.array([1.0, 0, 0]), X)
+    st = modules._new_state()
+    st.landmarks = np.arange(3 * n_land, dtype=np.float64).reshape(n_land, 3) + 50
+    st.keypoints = np.arange(2 * n_land, dtype=np.float64).reshape(n_land, 2) + 10
+    st.reproError = np.array([0.5, 1.5, 1.0])[:n_land]
+    st.candidate_keypoints = xy1
+    st.candidate_first_keypoints = xy0
+    st.candidate_first_poses = [pose0] * n_cand
+    st.candidate_time_indxs = np.array([-1, -1, -3, -10, -2, -1])[:n_cand]
+    return st, pose1, X
+
+
+def test_method_policy_promotes_ages_and_drops(oracle_geometry):
+    """modules/VisualOdometry.m:106-139."""
+    st, pose1, X = scripted_state()
+    vo = modules.VisualOdometry(modules.CameraParams(K), (376, 1241), angularThreshold=1.0, maxTemporalRecall=10,
+                                maxNumLandmarks=100, maxReprojectionError=2)
+    vo.tracker = FakeTracker([1, 1, 1, 1, 0, 1])             # candidate 4 fails tracking: dropped (:87)
+    cs = modules._new_state(); cs.landmarks = st.landmarks; cs.keypoints = st.keypoints; cs.reproError = st.reproError
+    out, tracked = vo.candidateTriangulation(None, st, None, cs, pose1)
+    assert len(tracked) == 5
+    # near candidates 0, 2, 5 become landmarks in candidate order, appended after the old ones
+    assert len(out.landmarks) == 3 + 3
+    np.testing.assert_allclose(out.landmarks[3:], X[[0, 2, 5]], atol=1e-6)
+    assert len(out.reproError) == 6 and (out.reproError[3:] < 1e-6).all()
+    # far candidate 1 (age -1) is kept and aged; far candidate 3 (age -10 = -maxTemporalRecall) is dropped (:130)
+    assert list(out.candidate_time_indxs) == [-2]
+    np.testing.assert_allclose(out.candidate_keypoints, st.candidate_keypoints[[1]])
+    assert len(out.candidate_first_poses) == 1
+
+
+def test_method_policy_replaces_the_worst_landmark_at_the_cap(oracle_geometry):
+    """:116-127: at the cap a new landmark evicts the landmark with the largest reprojection error,
+    the maximum being taken before the iteration's edits (:89)."""
+    st, pose1, X = scripted_state()
+    vo = modules.VisualOdometry(modules.CameraParams(K), (376, 1241), maxNumLandmarks=3, maxReprojectionError=2)
+    vo.tracker = FakeTracker([1, 0, 0, 0, 0, 0])
+    cs = modules._new_state(); cs.landmarks = st.landmarks; cs.keypoints = st.keypoints; cs.reproError = st.reproError
+    out, _ = vo.candidateTriangulation(None, st, None, cs, pose1)
+    assert len(out.landmarks) == 3
+    np.testing.assert_allclose(out.landmarks[:2], st.landmarks[[0, 2]])      # landmark 1 (error 1.5) evicted
+    np.testing.assert_allclose(out.landmarks[2], X[0], atol=1e-6)
+    assert list(np.round(out.reproError[:2], 6)) == [0.5, 1.0]
+
+
+def test_free_function_policy_is_fifo(oracle_geometry):
+    """modules/candidateTriangulation.m:88-93: at the cap the OLDEST landmark is dropped."""
+    st, pose1, X = scripted_state()
+    trk = FakeTracker([1, 1, 1, 1, 1, 1])
+    out, tracked = modules.candidateTriangulation(None, st, None, pose1, modules.CameraParams(K), trk,
+                                                  max_temporal_recall=10, admissible_angular_threshold=1.0,
+                                                  max_landmarks=4, max_reprojection_err=2)
+    assert len(tracked) == 6 and not hasattr(out, "reproError")
+    # 3 old landmarks + near candidates 0, 2, 4, 5 through a 4-slot FIFO -> the last four additions survive
+    np.testing.assert_allclose(out.landmarks, X[[0, 2, 4, 5]], atol=1e-6)
+    assert list(out.candidate_time_indxs) == [-2]            # far candidate 1 aged, far candidate 3 expired
+
+
+def test_klt_tracker_option_checks():
+    t = modules.KLTTracker()
+    assert (t.NumPyramidLevels, t.MaxBidirectionalError, t.BlockSize, t.MaxIterations) == (4, 2.0, (41, 41), 50)
+    for bad in ((40, 41), (3, 3), (41,)):
+        with pytest.raises(ValueError):
+            modules.KLTTracker(BlockSize=bad)
+    with pytest.raises(ValueError):
+        modules.KLTTracker(NumPyramidLevels=0)
+
+
+def test_camera_params_hold_the_transposed_intrinsics():
+    cp = modules.CameraParams(K)
+    np.testing.assert_array_equal(cp.IntrinsicMatrix, K.T)   # utils/dataLoaderKitti.m:50-53

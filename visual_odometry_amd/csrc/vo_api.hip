@@ -48,8 +48,8 @@ int vo_ctx_create(int device, vo_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, 4 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->d_counters, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_counters, 0, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long)) != hipSuccess) {
         vo_ctx_destroy(c);
         return VO_ERR_HIP;
     }
@@ -64,8 +64,6 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& f : c->frames) {
         if (f.I) (void)hipFree(f.I);
-        if (f.Gu) (void)hipFree(f.Gu);
-        if (f.Gv) (void)hipFree(f.Gv);
         if (f.img) (void)hipFree(f.img);
     }
     for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
@@ -92,9 +90,14 @@ const char* vo_ctx_last_error(vo_ctx* ctx) { return ctx ? ctx->last_error.c_str(
 
 int vo_ctx_read_counters(vo_ctx* ctx, uint64_t out[4], int reset) {
     if (!ctx || !out) return VO_ERR_BAD_ARG;
-    VO_HIP_CHECK(ctx, hipMemcpyAsync(out, ctx->d_counters, 32, hipMemcpyDeviceToHost, ctx->stream));
-    if (reset) VO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, 32, ctx->stream));
+    std::vector<unsigned long long> h(VO_COUNTER_SHARDS * 4);
+    const size_t bytes = h.size() * sizeof(unsigned long long);
+    VO_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), ctx->d_counters, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) VO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_counters, 0, bytes, ctx->stream));
     VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 4; ++k) out[k] = 0;
+    for (int s = 0; s < VO_COUNTER_SHARDS; ++s)
+        for (int k = 0; k < 4; ++k) out[k] += h[4 * s + k];
     return VO_OK;
 }
 int vo_timer_start(vo_ctx* ctx) {
@@ -124,12 +127,8 @@ static int frame_prepare(vo_ctx* ctx, vo_pyr* f, int nu, int nv, int levels) {
     if ((size_t)tot > f->cap) {
         VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (f->I) (void)hipFree(f->I);
-        if (f->Gu) (void)hipFree(f->Gu);
-        if (f->Gv) (void)hipFree(f->Gv);
-        f->I = f->Gu = f->Gv = nullptr; f->cap = 0;
+        f->I = nullptr; f->cap = 0;
         VO_HIP_CHECK(ctx, hipMalloc((void**)&f->I, tot * sizeof(float)));
-        VO_HIP_CHECK(ctx, hipMalloc((void**)&f->Gu, tot * sizeof(float)));
-        VO_HIP_CHECK(ctx, hipMalloc((void**)&f->Gv, tot * sizeof(float)));
         f->cap = (size_t)tot;
     }
     f->nu = nu; f->nv = nv; f->levels = levels; f->total = tot;

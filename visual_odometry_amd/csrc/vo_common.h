@@ -9,7 +9,9 @@
 #define VO_MAX_LEVELS 8
 #define VO_MIN_EIG 1e-3f
 
-struct vo_pyr {            // one frame slot: float pyramid + Sobel/8 gradients, all levels contiguous
+#define VO_COUNTER_SHARDS 256 // counters are sharded by keypoint / block index to avoid one hot word
+
+struct vo_pyr {            // one frame slot: float pyramid, all levels contiguous
     bool valid = false;
     uint64_t key = 0;      // host-side content hash (host API cache)
     uint64_t stamp = 0;    // LRU
@@ -18,9 +20,7 @@ struct vo_pyr {            // one frame slot: float pyramid + Sobel/8 gradients,
     long offs[VO_MAX_LEVELS];
     long total = 0;
     float* I = nullptr;    // total floats
-    float* Gu = nullptr;
-    float* Gv = nullptr;
-    size_t cap = 0;        // floats allocated per plane
+    size_t cap = 0;        // floats allocated
     uint8_t* img = nullptr; // device copy of the uint8 image (host API)
     size_t img_cap = 0;
 };
@@ -37,7 +37,7 @@ struct vo_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     vo_pyr frames[VO_NUM_FRAME_SLOTS];
     uint64_t clock = 0;
-    unsigned long long* d_counters = nullptr; // 4 x u64
+    unsigned long long* d_counters = nullptr; // VO_COUNTER_SHARDS x 4 u64
     vo_buf scratch[16];                        // purpose-indexed scratch (see vo_api.hip)
     std::string last_error;
 };
@@ -69,12 +69,13 @@ int vo_launch_response(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int sc
 int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is_rows, const float* d_eu,
                      const float* d_ev, int n_exist, const vo_sel_opts* o, vo_sel_work* w, float* d_out_u,
                      float* d_out_v, int32_t* d_out_lin, double* d_out_metric, int32_t* d_out_count);
+int vo_greedy_num_blocks(long n);
 int vo_launch_greedy(vo_ctx* ctx, double* d_scores_work, int nu, int nv, int num, int r, int32_t* d_out_uv,
                      unsigned long long* d_tmp);
 
 struct vo_strides { long xi, xc; }; // element (i, c) at base[i*xi + c*xc]
 int vo_launch_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, vo_strides sxy,
-                          const double* d_poses0, int pose_col_major, const int32_t* d_pose_idx, int C,
+                          const double* d_poses0, int pose_col_major, const int32_t* d_pose_idx, int C, int P,
                           const double* d_pose1, const double* d_K, double* d_X, vo_strides sX,
                           double* d_reproj, double* d_angle, uint8_t* d_valid);
 int vo_launch_angle(vo_ctx* ctx, const double* d_X, vo_strides sX, int n, const double* d_pose0,
@@ -87,5 +88,5 @@ int vo_launch_reproj(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
 struct vo_ransac_work { double* Rt; int32_t* cnt; unsigned long long* cost; };
 int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int M,
                      const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
-                     vo_ransac_work* w, void* d_out, uint8_t* d_inliers);
+                     const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers);
 int vo_launch_p3p_batch(vo_ctx* ctx, const double* d_P, const double* d_f, int n, double* d_poses);

@@ -1,0 +1,234 @@
+// vo_geom.hip -- per-candidate geometry, one thread per candidate, IEEE double in the oracle's
+// operation order (compiled with -ffp-contract=off): two-view linear DLT triangulation
+// (modules/VisualOdometry.m:93-101, old/linearTriangulation.m:28-39), reprojection error
+// (modules/VisualOdometry.m:48-61), bearing angle (utils/calculateAngleDeg.m:7-10) and cheirality
+// (modules/isInFrontOfCamera.m:8-11).  Conventions: oracle/geom.c header.
+//
+// Bound: ~60 algorithmic bytes and ~1.5 kflop (FP64) per candidate: launch-latency / HBM bound.
+#include "vo_common.h"
+
+namespace {
+
+struct M43 { double m[12]; }; // 4x3 row-major
+
+__device__ __forceinline__ void load43(const double* p, int col_major, double* out) {
+    if (col_major) {
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 3; ++c) out[r * 3 + c] = p[c * 4 + r];
+    } else {
+        for (int k = 0; k < 12; ++k) out[k] = p[k];
+    }
+}
+
+__device__ __forceinline__ void camera_matrix(const double* pose, const double* K, double* cam) {
+    double E[12];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) E[i * 3 + j] = pose[j * 3 + i];
+    for (int j = 0; j < 3; ++j)
+        E[9 + j] = -((pose[9] * pose[j * 3 + 0] + pose[10] * pose[j * 3 + 1]) + pose[11] * pose[j * 3 + 2]);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j)
+            cam[i * 3 + j] = (E[i * 3 + 0] * K[j * 3 + 0] + E[i * 3 + 1] * K[j * 3 + 1]) + E[i * 3 + 2] * K[j * 3 + 2];
+}
+
+__device__ __forceinline__ double angle_deg(const double* X, const double* c0, const double* c1) {
+    double a[3], b[3];
+    for (int i = 0; i < 3; ++i) { a[i] = X[i] - c0[i]; b[i] = X[i] - c1[i]; }
+    double dot = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+    double na = sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]);
+    double nb = sqrt((b[0] * b[0] + b[1] * b[1]) + b[2] * b[2]);
+    double c = dot / (na * nb);
+    if (c > 1.0) c = 1.0;
+    if (c < -1.0) c = -1.0;
+    return acos(c) * (180.0 / 3.14159265358979323846);
+}
+
+__device__ __forceinline__ void project(const double* cam, const double* X, double& u, double& v, double& w) {
+    double pu = ((X[0] * cam[0] + X[1] * cam[3]) + X[2] * cam[6]) + cam[9];
+    double pv = ((X[0] * cam[1] + X[1] * cam[4]) + X[2] * cam[7]) + cam[10];
+    double pw = ((X[0] * cam[2] + X[1] * cam[5]) + X[2] * cam[8]) + cam[11];
+    u = pu / pw; v = pv / pw; w = pw;
+}
+
+// one-sided Jacobi, 12 sweeps, same pair order as oracle/geom.c svd4_last.  Fully unrolled index
+// arithmetic keeps A and V in registers.
+__device__ void svd4_last(double* A, double* vout) {
+    double V[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    alpha += A[k * 4 + p] * A[k * 4 + p];
+                    beta += A[k * 4 + q] * A[k * 4 + q];
+                    gamma += A[k * 4 + p] * A[k * 4 + q];
+                }
+                if (gamma == 0.0) continue;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    double ap = A[k * 4 + p], aq = A[k * 4 + q];
+                    A[k * 4 + p] = c * ap - s * aq; A[k * 4 + q] = s * ap + c * aq;
+                    double vp = V[k * 4 + p], vq = V[k * 4 + q];
+                    V[k * 4 + p] = c * vp - s * vq; V[k * 4 + q] = s * vp + c * vq;
+                }
+            }
+    }
+    int best = 0; double bn = INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double nn = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nn += A[k * 4 + j] * A[k * 4 + j];
+        if (nn < bn) { bn = nn; best = j; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double v = V[k * 4 + 0];
+        if (best == 1) v = V[k * 4 + 1];
+        if (best == 2) v = V[k * 4 + 2];
+        if (best == 3) v = V[k * 4 + 3];
+        vout[k] = v;
+    }
+}
+
+struct TriArgs {
+    const double *xy0, *xy1; vo_strides sxy;
+    const double* poses0; int pose_col_major; const int32_t* pose_idx; int C, P;
+    const double *pose1, *K;
+    double* X; vo_strides sX; double *reproj, *angle; uint8_t* valid;
+};
+
+__global__ __launch_bounds__(256) void k_triangulate(TriArgs a) {
+    __shared__ double s_cam1[12], s_pose1[12], s_K[9];
+    if (threadIdx.x == 0) {
+        double p1[12], K[9];
+        load43(a.pose1, a.pose_col_major, p1);
+        for (int k = 0; k < 9; ++k) K[k] = a.K[k];
+        double cam[12];
+        camera_matrix(p1, K, cam);
+        for (int k = 0; k < 12; ++k) { s_cam1[k] = cam[k]; s_pose1[k] = p1[k]; }
+        for (int k = 0; k < 9; ++k) s_K[k] = K[k];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.C) return;
+    int pi = a.pose_idx ? a.pose_idx[i] : i;
+    if (pi < 0 || pi >= a.P) { // invalid table index: flag the candidate instead of reading out of bounds
+        a.valid[i] = 0; a.reproj[i] = __builtin_nan(""); a.angle[i] = __builtin_nan("");
+        for (int c = 0; c < 3; ++c) a.X[i * a.sX.xi + c * a.sX.xc] = __builtin_nan("");
+        return;
+    }
+    double pose0[12], K[9], cam0[12], cam1[12];
+    load43(a.poses0 + 12 * (long)pi, a.pose_col_major, pose0);
+    for (int k = 0; k < 9; ++k) K[k] = s_K[k];
+    for (int k = 0; k < 12; ++k) cam1[k] = s_cam1[k];
+    camera_matrix(pose0, K, cam0);
+    const double x0 = a.xy0[i * a.sxy.xi], y0 = a.xy0[i * a.sxy.xi + a.sxy.xc];
+    const double x1 = a.xy1[i * a.sxy.xi], y1 = a.xy1[i * a.sxy.xi + a.sxy.xc];
+    double A[16], h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        A[0 * 4 + k] = x0 * cam0[k * 3 + 2] - cam0[k * 3 + 0];
+        A[1 * 4 + k] = y0 * cam0[k * 3 + 2] - cam0[k * 3 + 1];
+        A[2 * 4 + k] = x1 * cam1[k * 3 + 2] - cam1[k * 3 + 0];
+        A[3 * 4 + k] = y1 * cam1[k * 3 + 2] - cam1[k * 3 + 1];
+    }
+    svd4_last(A, h);
+    double Xi[3] = {h[0] / h[3], h[1] / h[3], h[2] / h[3]};
+    double u, v, w0, w1;
+    project(cam0, Xi, u, v, w0);
+    const double e0 = sqrt((u - x0) * (u - x0) + (v - y0) * (v - y0));
+    project(cam1, Xi, u, v, w1);
+    const double e1 = sqrt((u - x1) * (u - x1) + (v - y1) * (v - y1));
+    for (int c = 0; c < 3; ++c) a.X[i * a.sX.xi + c * a.sX.xc] = Xi[c];
+    a.reproj[i] = 0.5 * (e0 + e1);
+    a.valid[i] = (uint8_t)(w0 > 0.0 && w1 > 0.0);
+    a.angle[i] = angle_deg(Xi, pose0 + 9, s_pose1 + 9);
+}
+
+__global__ __launch_bounds__(256) void k_angle(const double* X, vo_strides sX, int n, const double* pose0,
+                                               const double* pose1, int pose_col_major, double* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double p0[12], p1[12], Xi[3];
+    load43(pose0, pose_col_major, p0);
+    load43(pose1, pose_col_major, p1);
+    for (int c = 0; c < 3; ++c) Xi[c] = X[i * sX.xi + c * sX.xc];
+    out[i] = angle_deg(Xi, p0 + 9, p1 + 9);
+}
+
+__global__ __launch_bounds__(256) void k_in_front(const double* cam_, int cam_col_major, const double* X, vo_strides sX,
+                                                  int n, uint8_t* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double cam[12];
+    load43(cam_, cam_col_major, cam);
+    const double x = X[i * sX.xi], y = X[i * sX.xi + sX.xc], z = X[i * sX.xi + 2 * sX.xc];
+    const double w = ((x * cam[2] + y * cam[5]) + z * cam[8]) + cam[11];
+    out[i] = (uint8_t)(w > 0.0);
+}
+
+__global__ __launch_bounds__(256) void k_reproj(const double* xy, vo_strides sxy, const double* X, vo_strides sX, int n,
+                                                const double* pose_, int pose_col_major, const double* K_, double* err) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double pose[12], K[9], cam[12], Xi[3];
+    load43(pose_, pose_col_major, pose);
+    for (int k = 0; k < 9; ++k) K[k] = K_[k];
+    camera_matrix(pose, K, cam);
+    for (int c = 0; c < 3; ++c) Xi[c] = X[i * sX.xi + c * sX.xc];
+    double u, v, w;
+    project(cam, Xi, u, v, w);
+    const double du = xy[i * sxy.xi] - u, dv = xy[i * sxy.xi + sxy.xc] - v;
+    err[i] = sqrt(du * du + dv * dv);
+}
+
+} // namespace
+
+int vo_launch_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, vo_strides sxy,
+                          const double* d_poses0, int pose_col_major, const int32_t* d_pose_idx, int C, int P,
+                          const double* d_pose1, const double* d_K, double* d_X, vo_strides sX,
+                          double* d_reproj, double* d_angle, uint8_t* d_valid) {
+    if (C <= 0) return VO_OK;
+    TriArgs a;
+    a.xy0 = d_xy0; a.xy1 = d_xy1; a.sxy = sxy; a.poses0 = d_poses0; a.pose_col_major = pose_col_major;
+    a.pose_idx = d_pose_idx; a.C = C; a.P = P; a.pose1 = d_pose1; a.K = d_K; a.X = d_X; a.sX = sX;
+    a.reproj = d_reproj; a.angle = d_angle; a.valid = d_valid;
+    hipLaunchKernelGGL(k_triangulate, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, a);
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}
+
+int vo_launch_angle(vo_ctx* ctx, const double* d_X, vo_strides sX, int n, const double* d_pose0,
+                    const double* d_pose1, int pose_col_major, double* d_angle) {
+    if (n <= 0) return VO_OK;
+    hipLaunchKernelGGL(k_angle, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_X, sX, n, d_pose0, d_pose1,
+                       pose_col_major, d_angle);
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}
+
+int vo_launch_in_front(vo_ctx* ctx, const double* d_cam, int cam_col_major, const double* d_X, vo_strides sX,
+                       int n, uint8_t* d_valid) {
+    if (n <= 0) return VO_OK;
+    hipLaunchKernelGGL(k_in_front, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_cam, cam_col_major, d_X, sX, n, d_valid);
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}
+
+int vo_launch_reproj(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int n,
+                     const double* d_pose, int pose_col_major, const double* d_K, double* d_err) {
+    if (n <= 0) return VO_OK;
+    hipLaunchKernelGGL(k_reproj, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_xy, sxy, d_X, sX, n, d_pose,
+                       pose_col_major, d_K, d_err);
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}

@@ -2,13 +2,20 @@
 // Replaces vision.PointTracker as driven by KLTTracker.track (modules/KLTTracker.m:22-41; called
 // at modules/VisualOdometry.m:71,278).  Normative algorithm: oracle/vo_oracle.h N3-N5.
 //
-// Mapping: one 64-lane workgroup (= one wave) owns one keypoint for the forward and the backward
-// pass.  The wu x wv window is dealt out lane-cyclically (pixel id = k*64 + lane); the template
-// (T, Tu, Tv) lives in registers for the whole level; the search patch of the other image is
-// staged once into LDS with a margin of LK_M pixels and re-staged only when the estimate walks out
-// of it, so an iteration reads nothing but LDS: 4 taps per pixel with weights shared by the window.
-// Bound: FP32 VALU + LDS bandwidth, HBM traffic ~ the pyramids only (L2/MALL hits).
-// Algorithmic flops: set-up 24 flop/px, iteration 11 flop/px (counters[0], [2] count them).
+// Mapping.  One 64-lane workgroup (= one wave) owns one keypoint for the forward and the backward
+// pass.  The wu x wv window is cut into LU x LV rectangular blocks of BW x BH pixels, one block per
+// lane, so that a lane's bilinear taps overlap: (BW+1)(BH+1) LDS reads serve BW*BH pixels (1.4
+// reads/pixel for the 41x41 window instead of 4) and the interpolation is separable in registers.
+// The template (T, Tu, Tv) lives in registers for a whole level; the gradients are the Sobel/8
+// operator applied to the sub-pixel-sampled template itself, so a frame's pyramid is ONE float
+// plane per level.  The search patch of the other image is staged into LDS once per level with a
+// margin of LK_M pixels and re-staged only when the estimate walks out of it: an iteration touches
+// nothing but LDS and registers.  Patch pitches are chosen so that the 32-lane halves of a wave hit
+// distinct banks (at most 2-way on a handful of lanes).  Wave sums use DPP row operations.
+//
+// Bound: FP32 VALU (+ LDS bandwidth); HBM traffic is the pyramids only (L2 / Infinity Cache hits).
+// Algorithmic flops: set-up 24 flop/px, iteration 11 flop/px; ctx counters [0] and [2]
+// count executed iterations and set-ups.
 #include "vo_common.h"
 
 namespace {
@@ -16,58 +23,74 @@ namespace {
 constexpr int LK_M = 3; // LDS patch margin in pixels
 
 struct LKArgs {
-    const float *AI, *AGu, *AGv, *BI, *BGu, *BGv;
+    const float *A, *B;
     int nus[VO_MAX_LEVELS], nvs[VO_MAX_LEVELS];
     long offs[VO_MAX_LEVELS];
-    int levels, wu, wv, PW, PH, npx, max_iters, n;
-    double eps2, max_bidir;
+    int levels, wu, wv, npx, max_iters, n;
+    float eps2;
+    double max_bidir;
     const double *pu, *pv;
     double *qu, *qv;
     uint8_t* valid;
     float *score, *fb;
-    unsigned long long* counters;
+    unsigned long long* counters; // VO_COUNTER_SHARDS x 4
 };
+
+template <int BW_, int BH_, int LU_, int LV_, int PW_, bool COL_>
+struct Cfg {
+    static constexpr int BW = BW_, BH = BH_, LU = LU_, LV = LV_, PW = PW_;
+    static constexpr bool COL = COL_;
+    static constexpr int PH = LV * BH + 1 + 2 * LK_M;
+    static constexpr int MAXU = LU * BW, MAXV = LV * BH;
+    static_assert(PW >= LU * BW + 1 + 2 * LK_M, "patch pitch too small");
+    static_assert(LU * LV <= 64, "more blocks than lanes");
+};
+// pitches from a bank-conflict search over (lane -> block) orders, see DESIGN.md
+using CfgS = Cfg<3, 3, 7, 7, 39, false>;  // windows up to 21 x 21
+using CfgM = Cfg<5, 4, 7, 8, 43, true>;   // up to 35 x 32
+using CfgL = Cfg<6, 5, 7, 9, 49, false>;  // up to 42 x 45 (the reference's 41 x 41)
+using CfgX = Cfg<7, 7, 8, 8, 68, true>;   // up to 56 x 56 (51 x 51 of module_tests/updateW2D3D_test.m:20)
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) x += __shfl_xor(x, s, 64);
-    return x;
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROWMASK, 0xf, false));
+}
+// sum over the 64 lanes, result uniform
+__device__ __forceinline__ float wave_sum(float x) {
+    x += dpp_mov<0xb1, 0xf>(x);  // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4e, 0xf>(x);  // quad_perm [2,3,0,1]
+    x += dpp_mov<0x114, 0xf>(x); // row_shr:4
+    x += dpp_mov<0x118, 0xf>(x); // row_shr:8
+    x += dpp_mov<0x142, 0xa>(x); // row_bcast:15
+    x += dpp_mov<0x143, 0xc>(x); // row_bcast:31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 
-__device__ __forceinline__ void stage(float* patch, const float* __restrict__ img, int nu, int nv, int ou,
-                                      int ov, int PW, int PH, int lane) {
+// stage the whole PW x PH patch (replicate-clamped coordinates) -- every LDS word a lane can read
+// holds image data, so masked pixels never see NaN garbage
+template <class C>
+__device__ __forceinline__ void stage(float* patch, const float* __restrict__ img, int nu, int nv, int ou, int ov,
+                                      int lane) {
     __syncthreads();
-    for (int r = 0; r < PH; ++r) {
-        const float* row = img + (long)clampi(ov + r, 0, nv - 1) * nu;
-        for (int c = lane; c < PW; c += 64) patch[r * PW + c] = row[clampi(ou + c, 0, nu - 1)];
+    constexpr int TOT = C::PW * C::PH;
+#pragma unroll 8
+    for (int idx = lane; idx < TOT; idx += 64) {
+        const int r = idx / C::PW, c = idx - r * C::PW;
+        patch[idx] = img[(long)clampi(ov + r, 0, nv - 1) * nu + clampi(ou + c, 0, nu - 1)];
     }
     __syncthreads();
 }
 
-struct Bil {
-    float w00, w10, w01, w11;
-    int base;
-};
-__device__ __forceinline__ Bil make_bil(float fu, float fv, int fi, int fj, int PW) {
-    Bil b;
-    b.w00 = (1.0f - fu) * (1.0f - fv); b.w10 = fu * (1.0f - fv);
-    b.w01 = (1.0f - fu) * fv; b.w11 = fu * fv;
-    b.base = fj * PW + fi;
-    return b;
-}
-__device__ __forceinline__ float tap(const float* patch, int o, int PW, const Bil& b) {
-    return b.w00 * patch[o] + b.w10 * patch[o + 1] + b.w01 * patch[o + PW] + b.w11 * patch[o + PW + 1];
-}
-
 // one direction A -> B (N4).  returns flags: bit0 lost, bit1 flat at level 0
-template <int K>
-__device__ int lk_dir(const LKArgs& a, const float* AI, const float* AGu, const float* AGv, const float* BI,
-                      double su, double sv, float* patch, const int (&off)[K], int lane, double& qu,
-                      double& qv, float& ssd_out, unsigned& iters, unsigned& setups) {
-    float T[K], Tu[K], Tv[K];
-    const int PW = a.PW, PH = a.PH, ru = (a.wu - 1) / 2, rv = (a.wv - 1) / 2;
+template <class C>
+__device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float* __restrict__ B, double su, double sv,
+                      float* patch, int lane, int lbase, int bi0, int bj0, double& qu, double& qv, float& ssd_out,
+                      unsigned& iters, unsigned& setups) {
+    constexpr int BW = C::BW, BH = C::BH, PW = C::PW;
+    float T[BH][BW], Tu[BH][BW], Tv[BH][BW];
+    const int ru = (a.wu - 1) / 2, rv = (a.wv - 1) / 2;
     const int nu0 = a.nus[0], nv0 = a.nvs[0];
     double gu = 0, gv = 0;
     int flags = 0;
@@ -76,38 +99,56 @@ __device__ int lk_dir(const LKArgs& a, const float* AI, const float* AGu, const 
         const int nu = a.nus[l], nv = a.nvs[l];
         const long lo = a.offs[l];
         const double plu = su / s, plv = sv / s;
-        {
+        float sxx = 0, sxy = 0, syy = 0;
+        {   // ---- template set-up: E = samples on the window grown by one pixel, Sobel/8 of E ----
             const double flu = floor(plu), flv = floor(plv);
-            const int iu = (int)flu, iv = (int)flv;
-            const Bil b = make_bil((float)(plu - flu), (float)(plv - flv), LK_M, LK_M, PW);
-            const int ou = iu - ru - LK_M, ov = iv - rv - LK_M;
-            stage(patch, AI + lo, nu, nv, ou, ov, PW, PH, lane);
+            const float fu = (float)(plu - flu), fv = (float)(plv - flv);
+            stage<C>(patch, A + lo, nu, nv, (int)flu - ru - 1, (int)flv - rv - 1, lane);
+            float E[BH + 2][BW + 2];
+            float hp[BW + 2];
 #pragma unroll
-            for (int k = 0; k < K; ++k) T[k] = tap(patch, off[k] + b.base, PW, b);
-            stage(patch, AGu + lo, nu, nv, ou, ov, PW, PH, lane);
+            for (int r = 0; r < BH + 3; ++r) {
+                float p[BW + 3], h[BW + 2];
 #pragma unroll
-            for (int k = 0; k < K; ++k) Tu[k] = (k * 64 + lane < a.npx) ? tap(patch, off[k] + b.base, PW, b) : 0.0f;
-            stage(patch, AGv + lo, nu, nv, ou, ov, PW, PH, lane);
+                for (int c = 0; c < BW + 3; ++c) p[c] = patch[lbase + r * PW + c];
 #pragma unroll
-            for (int k = 0; k < K; ++k) Tv[k] = (k * 64 + lane < a.npx) ? tap(patch, off[k] + b.base, PW, b) : 0.0f;
+                for (int c = 0; c < BW + 2; ++c) h[c] = p[c] + fu * (p[c + 1] - p[c]);
+                if (r > 0) {
+#pragma unroll
+                    for (int c = 0; c < BW + 2; ++c) E[r - 1][c] = hp[c] + fv * (h[c] - hp[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < BW + 2; ++c) hp[c] = h[c];
+            }
+#pragma unroll
+            for (int j = 0; j < BH; ++j)
+#pragma unroll
+                for (int i = 0; i < BW; ++i) {
+                    const bool in = (bi0 + i < a.wu) && (bj0 + j < a.wv);
+                    const float tu = ((E[j][i + 2] - E[j][i]) + 2.0f * (E[j + 1][i + 2] - E[j + 1][i]) + (E[j + 2][i + 2] - E[j + 2][i])) * 0.125f;
+                    const float tv = ((E[j + 2][i] - E[j][i]) + 2.0f * (E[j + 2][i + 1] - E[j][i + 1]) + (E[j + 2][i + 2] - E[j][i + 2])) * 0.125f;
+                    T[j][i] = E[j + 1][i + 1];
+                    Tu[j][i] = in ? tu : 0.0f;
+                    Tv[j][i] = in ? tv : 0.0f;
+                    sxx += Tu[j][i] * Tu[j][i]; sxy += Tu[j][i] * Tv[j][i]; syy += Tv[j][i] * Tv[j][i];
+                }
             ++setups;
         }
-        float sxx = 0, sxy = 0, syy = 0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) { sxx += Tu[k] * Tu[k]; sxy += Tu[k] * Tv[k]; syy += Tv[k] * Tv[k]; }
-        const double Guu = wave_sum((double)sxx), Guv = wave_sum((double)sxy), Gvv = wave_sum((double)syy);
+        const double Guu = (double)wave_sum(sxx), Guv = (double)wave_sum(sxy), Gvv = (double)wave_sum(syy);
         const double dif = Guu - Gvv;
         const double mineig = ((Guu + Gvv) - sqrt(dif * dif + 4.0 * (Guv * Guv))) / (2.0 * (double)a.npx);
         const double det = Guu * Gvv - Guv * Guv;
-        double du = 0, dv = 0;
+        float du = 0, dv = 0;
         const bool flat = !(mineig >= (double)VO_MIN_EIG);
         if (flat) {
             if (l == 0) flags |= 2;
         } else {
+            const float iuu = (float)(Gvv / det), iuv = (float)(-Guv / det), ivv = (float)(Guu / det);
+            const double bu0 = plu + gu, bv0 = plv + gv;
             bool staged = false;
             int pou = 0, pov = 0;
             for (int it = 0; it < a.max_iters; ++it) {
-                const double cu = plu + gu + du, cv = plv + gv + dv;
+                const double cu = bu0 + (double)du, cv = bv0 + (double)dv;
                 if (!(cu * s >= 0.0 && cu * s <= (double)(nu0 - 1) && cv * s >= 0.0 && cv * s <= (double)(nv0 - 1))) {
                     flags |= 1;
                     break;
@@ -117,29 +158,43 @@ __device__ int lk_dir(const LKArgs& a, const float* AI, const float* AGu, const 
                 int fi = iu - ru - pou, fj = iv - rv - pov;
                 if (!staged || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) {
                     pou = iu - ru - LK_M; pov = iv - rv - LK_M;
-                    stage(patch, BI + lo, nu, nv, pou, pov, PW, PH, lane);
+                    stage<C>(patch, B + lo, nu, nv, pou, pov, lane);
                     staged = true;
                     fi = LK_M; fj = LK_M;
                 }
-                const Bil b = make_bil((float)(cu - flu), (float)(cv - flv), fi, fj, PW);
+                const float fu = (float)(cu - flu), fv = (float)(cv - flv);
+                const int base = lbase + fj * PW + fi;
                 float bu = 0, bv = 0;
+                float hp[BW];
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float e = T[k] - tap(patch, off[k] + b.base, PW, b);
-                    bu += e * Tu[k];
-                    bv += e * Tv[k];
+                for (int r = 0; r < BH + 1; ++r) {
+                    float p[BW + 1], h[BW];
+#pragma unroll
+                    for (int c = 0; c < BW + 1; ++c) p[c] = patch[base + r * PW + c];
+#pragma unroll
+                    for (int c = 0; c < BW; ++c) h[c] = p[c] + fu * (p[c + 1] - p[c]);
+                    if (r > 0) {
+#pragma unroll
+                        for (int c = 0; c < BW; ++c) {
+                            const float e = T[r - 1][c] - (hp[c] + fv * (h[c] - hp[c]));
+                            bu += e * Tu[r - 1][c];
+                            bv += e * Tv[r - 1][c];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < BW; ++c) hp[c] = h[c];
                 }
-                const double Bu = wave_sum((double)bu), Bv = wave_sum((double)bv);
+                const float Bu = wave_sum(bu), Bv = wave_sum(bv);
                 ++iters;
-                const double ddu = (Gvv * Bu - Guv * Bv) / det;
-                const double ddv = (Guu * Bv - Guv * Bu) / det;
+                const float ddu = iuu * Bu + iuv * Bv;
+                const float ddv = iuv * Bu + ivv * Bv;
                 du += ddu; dv += ddv;
                 if (ddu * ddu + ddv * ddv < a.eps2) break;
             }
         }
         if (flags & 1) break;
-        if (l > 0) { gu = 2.0 * (gu + du); gv = 2.0 * (gv + dv); }
-        else { gu = gu + du; gv = gv + dv; }
+        if (l > 0) { gu = 2.0 * (gu + (double)du); gv = 2.0 * (gv + (double)dv); }
+        else { gu = gu + (double)du; gv = gv + (double)dv; }
     }
     qu = su + gu; qv = sv + gv;
     if (!(flags & 1)) {
@@ -148,40 +203,54 @@ __device__ int lk_dir(const LKArgs& a, const float* AI, const float* AGu, const 
     ssd_out = 0.0f;
     if (!(flags & 1)) { // N5 residual at level 0; T holds the level-0 template
         const double flu = floor(qu), flv = floor(qv);
-        const int iu = (int)flu, iv = (int)flv;
-        stage(patch, BI, nu0, nv0, iu - ru - LK_M, iv - rv - LK_M, PW, PH, lane);
-        const Bil b = make_bil((float)(qu - flu), (float)(qv - flv), LK_M, LK_M, PW);
+        stage<C>(patch, B, nu0, nv0, (int)flu - ru - LK_M, (int)flv - rv - LK_M, lane);
+        const float fu = (float)(qu - flu), fv = (float)(qv - flv);
+        const int base = lbase + LK_M * PW + LK_M;
         float ssd = 0;
+        float hp[BW];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float e = T[k] - tap(patch, off[k] + b.base, PW, b);
-            ssd += (k * 64 + lane < a.npx) ? e * e : 0.0f;
+        for (int r = 0; r < BH + 1; ++r) {
+            float p[BW + 1], h[BW];
+#pragma unroll
+            for (int c = 0; c < BW + 1; ++c) p[c] = patch[base + r * PW + c];
+#pragma unroll
+            for (int c = 0; c < BW; ++c) h[c] = p[c] + fu * (p[c + 1] - p[c]);
+            if (r > 0) {
+#pragma unroll
+                for (int c = 0; c < BW; ++c) {
+                    const bool in = (bi0 + c < a.wu) && (bj0 + r - 1 < a.wv);
+                    const float e = T[r - 1][c] - (hp[c] + fv * (h[c] - hp[c]));
+                    ssd += in ? e * e : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < BW; ++c) hp[c] = h[c];
         }
-        ssd_out = (float)wave_sum((double)ssd);
+        ssd_out = wave_sum(ssd);
     }
     return flags;
 }
 
-template <int K>
+template <class C>
 __global__ __launch_bounds__(64) void k_lk(LKArgs a) {
-    extern __shared__ float patch[];
+    __shared__ float patch[C::PW * C::PH];
     const int lane = threadIdx.x, kp = blockIdx.x;
-    int off[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int id = k * 64 + lane;
-        const int j = id / a.wu, i = id - j * a.wu;
-        off[k] = id < a.npx ? j * a.PW + i : 0;
-    }
+    // lane -> block; lanes beyond LU*LV read block 0's pixels with an all-masked window
+    int lu, lv;
+    const bool live = lane < C::LU * C::LV;
+    if (C::COL) { lu = lane / C::LV; lv = lane - lu * C::LV; } else { lv = lane / C::LU; lu = lane - lv * C::LU; }
+    const int bi0 = live ? lu * C::BW : C::MAXU; // mask origin: >= wu masks every pixel
+    const int bj0 = live ? lv * C::BH : C::MAXV;
+    const int lbase = live ? (lv * C::BH) * C::PW + lu * C::BW : 0;
     const double p0u = a.pu[kp], p0v = a.pv[kp];
     unsigned iters = 0, setups = 0;
     double fu, fv, bu = 0, bv = 0;
     float ssd, ssd2;
-    const int fl = lk_dir<K>(a, a.AI, a.AGu, a.AGv, a.BI, p0u, p0v, patch, off, lane, fu, fv, ssd, iters, setups);
+    const int fl = lk_dir<C>(a, a.A, a.B, p0u, p0v, patch, lane, lbase, bi0, bj0, fu, fv, ssd, iters, setups);
     bool ok = (fl == 0);
     float fb = __builtin_nanf("");
     if (!(fl & 1) && a.max_bidir >= 0.0) {
-        const int fl2 = lk_dir<K>(a, a.BI, a.BGu, a.BGv, a.AI, fu, fv, patch, off, lane, bu, bv, ssd2, iters, setups);
+        const int fl2 = lk_dir<C>(a, a.B, a.A, fu, fv, patch, lane, lbase, bi0, bj0, bu, bv, ssd2, iters, setups);
         if (fl2 & 1) ok = false;
         else {
             const double eu = p0u - bu, ev = p0v - bv;
@@ -200,10 +269,16 @@ __global__ __launch_bounds__(64) void k_lk(LKArgs a) {
         }
         a.score[kp] = sc;
         if (a.fb) a.fb[kp] = fb;
-        atomicAdd(&a.counters[0], (unsigned long long)iters);
-        atomicAdd(&a.counters[1], 1ull);
-        atomicAdd(&a.counters[2], (unsigned long long)setups);
+        unsigned long long* cnt = a.counters + 4 * (kp & (VO_COUNTER_SHARDS - 1));
+        atomicAdd(&cnt[0], (unsigned long long)iters);
+        atomicAdd(&cnt[1], 1ull);
+        atomicAdd(&cnt[2], (unsigned long long)setups);
     }
+}
+
+template <class C>
+void launch(const LKArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_lk<C>, dim3(a.n), dim3(64), 0, st, a);
 }
 
 } // namespace
@@ -212,24 +287,21 @@ int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d
                   int wu, int wv, int max_iters, double eps, double max_bidir, double* d_qu, double* d_qv,
                   uint8_t* d_valid, float* d_score, float* d_fb) {
     if (n <= 0) return VO_OK;
-    if (!(wu & 1) || !(wv & 1) || wu < 3 || wv < 3 || max_iters < 1) { ctx->last_error = "klt: BlockSize must be odd >= 3"; return VO_ERR_BAD_ARG; }
+    if (!(wu & 1) || !(wv & 1) || wu < 3 || wv < 3 || max_iters < 1) { ctx->last_error = "klt: BlockSize must be odd >= 3, MaxIterations >= 1"; return VO_ERR_BAD_ARG; }
     if (A->nu != B->nu || A->nv != B->nv || A->levels != B->levels) { ctx->last_error = "klt: frame shapes differ"; return VO_ERR_BAD_ARG; }
     LKArgs a;
-    a.AI = A->I; a.AGu = A->Gu; a.AGv = A->Gv; a.BI = B->I; a.BGu = B->Gu; a.BGv = B->Gv;
+    a.A = A->I; a.B = B->I;
     for (int l = 0; l < A->levels; ++l) { a.nus[l] = A->nus[l]; a.nvs[l] = A->nvs[l]; a.offs[l] = A->offs[l]; }
-    a.levels = A->levels; a.wu = wu; a.wv = wv; a.PW = wu + 1 + 2 * LK_M; a.PH = wv + 1 + 2 * LK_M;
+    a.levels = A->levels; a.wu = wu; a.wv = wv;
     a.npx = wu * wv; a.max_iters = max_iters; a.n = n;
-    a.eps2 = eps * eps; a.max_bidir = max_bidir;
+    a.eps2 = (float)(eps * eps); a.max_bidir = max_bidir;
     a.pu = d_pu; a.pv = d_pv; a.qu = d_qu; a.qv = d_qv; a.valid = d_valid; a.score = d_score; a.fb = d_fb;
     a.counters = ctx->d_counters;
-    const size_t lds = (size_t)a.PW * a.PH * sizeof(float);
-    const int K = (a.npx + 63) / 64;
-    dim3 grid(n), block(64);
-    if (K <= 8) hipLaunchKernelGGL(k_lk<8>, grid, block, lds, ctx->stream, a);
-    else if (K <= 16) hipLaunchKernelGGL(k_lk<16>, grid, block, lds, ctx->stream, a);
-    else if (K <= 27) hipLaunchKernelGGL(k_lk<27>, grid, block, lds, ctx->stream, a);
-    else if (K <= 41) hipLaunchKernelGGL(k_lk<41>, grid, block, lds, ctx->stream, a);
-    else { ctx->last_error = "klt: BlockSize larger than 51x51 is not supported"; return VO_ERR_UNSUPPORTED; }
+    if (wu <= CfgS::MAXU && wv <= CfgS::MAXV) launch<CfgS>(a, ctx->stream);
+    else if (wu <= CfgM::MAXU && wv <= CfgM::MAXV) launch<CfgM>(a, ctx->stream);
+    else if (wu <= CfgL::MAXU && wv <= CfgL::MAXV) launch<CfgL>(a, ctx->stream);
+    else if (wu <= CfgX::MAXU && wv <= CfgX::MAXV) launch<CfgX>(a, ctx->stream);
+    else { ctx->last_error = "klt: BlockSize larger than 55 x 55 is not supported"; return VO_ERR_UNSUPPORTED; }
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }

@@ -1,0 +1,494 @@
+// vo_ransac.hip -- P3P-RANSAC localisation.  Replaces the estimateWorldCameraPose call of the pose
+// step (modules/VisualOdometry.m:285-289) with the open algorithm the reference carries in old/:
+// Kneip P3P (old/p3p.m:41-217), Ferrari quartic with complex intermediates
+// (old/solveQuartic.m:26-66) and the RANSAC loop of old/ransacLocalization.m:44-130.  Normative
+// details (Philox sample stream, MSAC cost, adaptive stop): oracle/p3p.c header, N9.
+//
+//   k_hyp      one thread per hypothesis: sample 3 indices (seeded Philox4x32-10 or a caller table),
+//              bearings, P3P -> 4 x (R_cw, t_cw)
+//   k_score    one 256-thread block per SC_HB hypotheses: every thread walks the points once and
+//              scores 4*SC_HB poses per point from LDS-broadcast pose rows; inlier counts and MSAC
+//              costs are integers, reduced across the wavefront by DPP/shuffle and across the four
+//              waves through LDS -- order independent, hence bit-exact
+//   k_best     one wavefront: sequential RANSAC semantics (strict-improvement updates, adaptive
+//              stop) evaluated as a chunked prefix scan
+//   k_inliers  inlier mask of the winning pose
+// All arithmetic is IEEE double in the oracle's operation order (-ffp-contract=off).
+// Bound: FP64 VALU (two IEEE divisions per pose x point); points and poses are L2/LDS resident.
+#include "vo_common.h"
+
+namespace {
+
+struct cpx { double re, im; };
+__device__ __forceinline__ cpx cmk(double a, double b) { cpx z; z.re = a; z.im = b; return z; }
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return cmk(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return cmk(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ cpx cscale(cpx a, double s) { return cmk(a.re * s, a.im * s); }
+__device__ __forceinline__ cpx cdivc(cpx a, cpx b) {
+    double d = b.re * b.re + b.im * b.im;
+    return cmk((a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d);
+}
+__device__ __forceinline__ cpx csqrt_(cpx z) {
+    if (z.re == 0.0 && z.im == 0.0) return cmk(0, 0);
+    double m = sqrt(z.re * z.re + z.im * z.im);
+    double t = sqrt(0.5 * (m + fabs(z.re)));
+    if (z.re >= 0.0) return cmk(t, z.im / (2.0 * t));
+    return cmk(fabs(z.im) / (2.0 * t), z.im < 0.0 ? -t : t);
+}
+__device__ __forceinline__ cpx ccbrt_(cpx z) {
+    if (z.re == 0.0 && z.im == 0.0) return cmk(0, 0);
+    double m = cbrt(sqrt(z.re * z.re + z.im * z.im));
+    double a = atan2(z.im, z.re) / 3.0;
+    return cmk(m * cos(a), m * sin(a));
+}
+
+// old/solveQuartic.m:26-66
+__device__ void solve_quartic(const double* f, cpx* roots) {
+    const double A = f[0], B = f[1], C = f[2], D = f[3], E = f[4];
+    const double A_pw2 = A * A, B_pw2 = B * B;
+    const double A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B;
+    const double A_pw4 = A_pw3 * A, B_pw4 = B_pw3 * B;
+    const double alpha = -3 * B_pw2 / (8 * A_pw2) + C / A;
+    const double beta = B_pw3 / (8 * A_pw3) - B * C / (2 * A_pw2) + D / A;
+    const double gamma = -3 * B_pw4 / (256 * A_pw4) + B_pw2 * C / (16 * A_pw3) - B * D / (4 * A_pw2) + E / A;
+    const double alpha_pw2 = alpha * alpha, alpha_pw3 = alpha_pw2 * alpha;
+    const double P = -alpha_pw2 / 12 - gamma;
+    const double Q = -alpha_pw3 / 108 + alpha * gamma / 3 - beta * beta / 8;
+    const cpx R = cadd(cmk(-Q / 2, 0), csqrt_(cmk(Q * Q / 4 + P * P * P / 27, 0)));
+    const cpx U = ccbrt_(R);
+    cpx y;
+    if (U.re == 0.0 && U.im == 0.0) y = csub(cmk(-5 * alpha / 6, 0), ccbrt_(cmk(Q, 0)));
+    else y = cadd(csub(cmk(-5 * alpha / 6, 0), cdivc(cmk(P, 0), cscale(U, 3.0))), U);
+    const cpx w = csqrt_(cadd(cmk(alpha, 0), cscale(y, 2.0)));
+    const cpx bw = cdivc(cmk(2 * beta, 0), w);
+    const cpx base = cadd(cmk(3 * alpha, 0), cscale(y, 2.0));
+    const cpx sp = csqrt_(cscale(cadd(base, bw), -1.0));
+    const cpx sm = csqrt_(cscale(csub(base, bw), -1.0));
+    const cpx off = cmk(-B / (4 * A), 0);
+    roots[0] = cadd(off, cscale(cadd(w, sp), 0.5));
+    roots[1] = cadd(off, cscale(csub(w, sp), 0.5));
+    roots[2] = cadd(off, cscale(cadd(cscale(w, -1.0), sm), 0.5));
+    roots[3] = cadd(off, cscale(csub(cscale(w, -1.0), sm), 0.5));
+}
+
+__device__ __forceinline__ void cross3(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ double dot3(const double* a, const double* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+__device__ __forceinline__ void matvec3(const double* M, const double* x, double* y) {
+    for (int i = 0; i < 3; ++i) y[i] = dot3(M + 3 * i, x);
+}
+__device__ __forceinline__ void cp3(double* d, const double* s) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+
+// old/p3p.m:41-217.  Pw: 3 world points (row i = point i); fv: 3 unit bearings.  poses: 4 x 12
+// [C(3) R(9 row-major, cam->world)]
+__device__ void p3p_device(const double* Pw, const double* fv, double* poses) {
+    for (int k = 0; k < 48; ++k) poses[k] = 0.0;
+    double P1[3], P2[3], P3[3], f1[3], f2[3], f3[3];
+    cp3(P1, Pw); cp3(P2, Pw + 3); cp3(P3, Pw + 6);
+    double v1[3], v2[3], cr[3];
+    for (int i = 0; i < 3; ++i) { v1[i] = P2[i] - P1[i]; v2[i] = P3[i] - P1[i]; }
+    cross3(v1, v2, cr);
+    if (sqrt(dot3(cr, cr)) == 0.0) return;
+    cp3(f1, fv); cp3(f2, fv + 3); cp3(f3, fv + 6);
+    double T[9], e3n;
+    {
+        double* e1 = T; double* e2 = T + 3; double* e3 = T + 6;
+        cp3(e1, f1);
+        cross3(f1, f2, e3);
+        e3n = sqrt(dot3(e3, e3));
+        for (int i = 0; i < 3; ++i) e3[i] /= e3n;
+        cross3(e3, e1, e2);
+    }
+    double f3t[3];
+    matvec3(T, f3, f3t);
+    if (f3t[2] > 0) {
+        cp3(f1, fv + 3); cp3(f2, fv); cp3(f3, fv + 6);
+        double* e1 = T; double* e2 = T + 3; double* e3 = T + 6;
+        cp3(e1, f1);
+        cross3(f1, f2, e3);
+        e3n = sqrt(dot3(e3, e3));
+        for (int i = 0; i < 3; ++i) e3[i] /= e3n;
+        cross3(e3, e1, e2);
+        matvec3(T, f3, f3t);
+        cp3(P1, Pw + 3); cp3(P2, Pw); cp3(P3, Pw + 6);
+    }
+    double N[9];
+    {
+        double* n1 = N; double* n2 = N + 3; double* n3 = N + 6;
+        double d[3], nn;
+        for (int i = 0; i < 3; ++i) n1[i] = P2[i] - P1[i];
+        nn = sqrt(dot3(n1, n1));
+        for (int i = 0; i < 3; ++i) n1[i] /= nn;
+        for (int i = 0; i < 3; ++i) d[i] = P3[i] - P1[i];
+        cross3(n1, d, n3);
+        nn = sqrt(dot3(n3, n3));
+        for (int i = 0; i < 3; ++i) n3[i] /= nn;
+        cross3(n3, n1, n2);
+    }
+    double P3n[3], d31[3], d21[3];
+    for (int i = 0; i < 3; ++i) { d31[i] = P3[i] - P1[i]; d21[i] = P2[i] - P1[i]; }
+    matvec3(N, d31, P3n);
+    const double d_12 = sqrt(dot3(d21, d21));
+    const double f_1 = f3t[0] / f3t[2], f_2 = f3t[1] / f3t[2];
+    const double p_1 = P3n[0], p_2 = P3n[1];
+    const double cos_beta = dot3(f1, f2);
+    double b = 1 / (1 - cos_beta * cos_beta) - 1;
+    if (cos_beta < 0) b = -sqrt(b); else b = sqrt(b);
+
+    const double f_1_pw2 = f_1 * f_1, f_2_pw2 = f_2 * f_2;
+    const double p_1_pw2 = p_1 * p_1, p_1_pw3 = p_1_pw2 * p_1, p_1_pw4 = p_1_pw3 * p_1;
+    const double p_2_pw2 = p_2 * p_2, p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2;
+    const double d_12_pw2 = d_12 * d_12, b_pw2 = b * b;
+
+    double fac[5];
+    fac[0] = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
+    fac[1] = 2 * p_2_pw3 * d_12 * b + 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * f_2 * p_2_pw3 * f_1 * d_12;
+    fac[2] = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 +
+             f_2_pw2 * p_2_pw4 + p_2_pw4 * f_1_pw2 + 2 * p_1 * p_2_pw2 * d_12 +
+             2 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b - p_2_pw2 * p_1_pw2 * f_1_pw2 +
+             2 * p_1 * p_2_pw2 * f_2_pw2 * d_12 - p_2_pw2 * d_12_pw2 * b_pw2 - 2 * p_1_pw2 * p_2_pw2;
+    fac[3] = 2 * p_1_pw2 * p_2 * d_12 * b + 2 * f_2 * p_2_pw3 * f_1 * d_12 - 2 * f_2_pw2 * p_2_pw3 * d_12 * b -
+             2 * p_1 * p_2 * d_12_pw2 * b;
+    fac[4] = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 + 2 * p_1_pw3 * d_12 -
+             p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 - 2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 +
+             p_2_pw2 * f_1_pw2 * p_1_pw2 + f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
+    cpx x[4];
+    solve_quartic(fac, x);
+
+    for (int i = 0; i < 4; ++i) {
+        const double xr = x[i].re;
+        const double cot_alpha = (-f_1 * p_1 / f_2 - xr * p_2 + d_12 * b) / (-f_1 * xr * p_2 / f_2 + p_1 - d_12);
+        const double cos_theta = xr;
+        const double st2 = 1 - xr * xr;
+        const double sin_theta = st2 >= 0 ? sqrt(st2) : 0.0;
+        const double sin_alpha = sqrt(1 / (cot_alpha * cot_alpha + 1));
+        double cos_alpha = sqrt(1 - sin_alpha * sin_alpha);
+        if (cot_alpha < 0) cos_alpha = -cos_alpha;
+        const double k = sin_alpha * b + cos_alpha;
+        double C[3] = {d_12 * cos_alpha * k, cos_theta * d_12 * sin_alpha * k, sin_theta * d_12 * sin_alpha * k};
+        double Cw[3];
+        for (int r = 0; r < 3; ++r)
+            Cw[r] = P1[r] + ((N[0 * 3 + r] * C[0] + N[1 * 3 + r] * C[1]) + N[2 * 3 + r] * C[2]);
+        const double R[9] = {-cos_alpha, -sin_alpha * cos_theta, -sin_alpha * sin_theta,
+                             sin_alpha, -cos_alpha * cos_theta, -cos_alpha * sin_theta,
+                             0, -sin_theta, cos_theta};
+        double NR[9], Rw[9];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                NR[r * 3 + c] = (N[0 * 3 + r] * R[c * 3 + 0] + N[1 * 3 + r] * R[c * 3 + 1]) + N[2 * 3 + r] * R[c * 3 + 2];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                Rw[r * 3 + c] = (NR[r * 3 + 0] * T[0 * 3 + c] + NR[r * 3 + 1] * T[1 * 3 + c]) + NR[r * 3 + 2] * T[2 * 3 + c];
+        cp3(poses + 12 * i, Cw);
+        for (int k2 = 0; k2 < 9; ++k2) poses[12 * i + 3 + k2] = Rw[k2];
+    }
+}
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], const uint32_t key[2]) {
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ void philox_sample3(uint64_t seed, uint32_t hyp, uint32_t m, int32_t* idx) {
+    uint32_t c[4] = {hyp, 0, 0, 0}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    philox4x32_10(c, key);
+    uint32_t i0 = c[0] % m;
+    uint32_t i1 = c[1] % (m - 1); if (i1 >= i0) ++i1;
+    uint32_t i2 = c[2] % (m - 2);
+    uint32_t lo = i0 < i1 ? i0 : i1, hi = i0 < i1 ? i1 : i0;
+    if (i2 >= lo) ++i2;
+    if (i2 >= hi) ++i2;
+    idx[0] = (int32_t)i0; idx[1] = (int32_t)i1; idx[2] = (int32_t)i2;
+}
+
+__device__ __forceinline__ void bearing(const double* K, double u, double v, double* f) {
+    double y = (v - K[5]) / K[4];
+    double x = ((u - K[2]) - K[1] * y) / K[0];
+    double n = sqrt((x * x + y * y) + 1.0);
+    f[0] = x / n; f[1] = y / n; f[2] = 1.0 / n;
+}
+
+struct HypArgs {
+    const double* xy; vo_strides sxy; const double* X; vo_strides sX; int M;
+    const double* K; int H; uint64_t seed; const int32_t* sample_idx; double* Rt;
+};
+
+__global__ __launch_bounds__(64) void k_hyp(HypArgs a) {
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.H) return;
+    double K[9];
+    for (int k = 0; k < 9; ++k) K[k] = a.K[k];
+    int32_t id[3];
+    bool ok = true;
+    if (a.sample_idx) {
+        for (int k = 0; k < 3; ++k) { id[k] = a.sample_idx[3 * h + k]; if (id[k] < 0 || id[k] >= a.M) ok = false; }
+    } else philox_sample3(a.seed, (uint32_t)h, (uint32_t)a.M, id);
+    double poses[48];
+    if (ok) {
+        double Pw[9], f[9];
+        for (int k = 0; k < 3; ++k) {
+            const long i = id[k];
+            for (int c = 0; c < 3; ++c) Pw[3 * k + c] = a.X[i * a.sX.xi + c * a.sX.xc];
+            bearing(K, a.xy[i * a.sxy.xi], a.xy[i * a.sxy.xi + a.sxy.xc], f + 3 * k);
+        }
+        p3p_device(Pw, f, poses);
+    } else {
+        for (int k = 0; k < 48; ++k) poses[k] = 0.0; // out-of-range table entry: a null hypothesis
+    }
+    for (int s = 0; s < 4; ++s) {
+        const double* C = poses + 12 * s; const double* Rwc = C + 3;
+        double R[9], t[3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) R[r * 3 + c] = Rwc[c * 3 + r];
+        for (int r = 0; r < 3; ++r) t[r] = -((R[r * 3] * C[0] + R[r * 3 + 1] * C[1]) + R[r * 3 + 2] * C[2]);
+        double* o = a.Rt + 48 * (long)h + 12 * s;
+        for (int k = 0; k < 9; ++k) o[k] = R[k];
+        for (int k = 0; k < 3; ++k) o[9 + k] = t[k];
+    }
+}
+
+__device__ __forceinline__ double reproj_e2(const double* R, const double* t, double K0, double K1, double K2,
+                                            double K4, double K5, double X0, double X1, double X2, double u, double v) {
+    double xc = ((R[0] * X0 + R[1] * X1) + R[2] * X2) + t[0];
+    double yc = ((R[3] * X0 + R[4] * X1) + R[5] * X2) + t[1];
+    double zc = ((R[6] * X0 + R[7] * X1) + R[8] * X2) + t[2];
+    double up = (K0 * xc + K1 * yc) + K2 * zc;
+    double vp = K4 * yc + K5 * zc;
+    double du = u - up / zc, dv = v - vp / zc;
+    return du * du + dv * dv;
+}
+
+constexpr int SC_HB = 2;          // hypotheses per block
+constexpr int SC_NS = 4 * SC_HB;  // poses per block
+
+struct ScoreArgs {
+    const double* xy; vo_strides sxy; const double* X; vo_strides sX; int M;
+    const double* K; int H; double thr2; const double* Rt; int32_t* cnt; unsigned long long* cost;
+    unsigned long long* counters;
+};
+
+__global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
+    __shared__ double sRt[SC_NS * 12];
+    __shared__ int s_cnt[4][SC_NS];
+    __shared__ unsigned long long s_cost[4][SC_NS];
+    const int h0 = blockIdx.x * SC_HB;
+    const int tid = threadIdx.x;
+    if (tid < SC_NS * 12) {
+        const int hs = tid / 12;             // pose within the block
+        const int h = h0 + hs / 4;
+        sRt[tid] = h < a.H ? a.Rt[48 * (long)h0 + tid] : 0.0;
+    }
+    __syncthreads();
+    const double K0 = a.K[0], K1 = a.K[1], K2 = a.K[2], K4 = a.K[4], K5 = a.K[5];
+    const double thr2 = a.thr2;
+    const unsigned long long qthr = (unsigned long long)(thr2 * 1048576.0);
+    int cnt[SC_NS];
+    unsigned long long cost[SC_NS];
+#pragma unroll
+    for (int s = 0; s < SC_NS; ++s) { cnt[s] = 0; cost[s] = 0; }
+    for (int i = tid; i < a.M; i += 256) {
+        const double X0 = a.X[i * a.sX.xi], X1 = a.X[i * a.sX.xi + a.sX.xc], X2 = a.X[i * a.sX.xi + 2 * a.sX.xc];
+        const double u = a.xy[i * a.sxy.xi], v = a.xy[i * a.sxy.xi + a.sxy.xc];
+#pragma unroll
+        for (int s = 0; s < SC_NS; ++s) {
+            const double e2 = reproj_e2(sRt + 12 * s, sRt + 12 * s + 9, K0, K1, K2, K4, K5, X0, X1, X2, u, v);
+            if (e2 < thr2) { ++cnt[s]; cost[s] += (unsigned long long)(e2 * 1048576.0); }
+            else cost[s] += qthr;
+        }
+    }
+    const int lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+    for (int s = 0; s < SC_NS; ++s) {
+        int c = cnt[s]; unsigned long long q = cost[s];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { c += __shfl_xor(c, d, 64); q += __shfl_xor(q, d, 64); }
+        if (lane == 0) { s_cnt[wid][s] = c; s_cost[wid][s] = q; }
+    }
+    __syncthreads();
+    if (tid < SC_NS) {
+        const int h = h0 + tid / 4;
+        if (h < a.H) {
+            a.cnt[4 * (long)h0 + tid] = (s_cnt[0][tid] + s_cnt[1][tid]) + (s_cnt[2][tid] + s_cnt[3][tid]);
+            a.cost[4 * (long)h0 + tid] = (s_cost[0][tid] + s_cost[1][tid]) + (s_cost[2][tid] + s_cost[3][tid]);
+        }
+    }
+    if (tid == 0 && a.counters) atomicAdd(&a.counters[4 * (blockIdx.x & (VO_COUNTER_SHARDS - 1)) + 3], (unsigned long long)min(SC_HB, a.H - h0));
+}
+
+// ---- sequential RANSAC semantics (old/ransacLocalization.m:86-124) as a chunked scan, one wave ----
+struct BState { int h, s, c; unsigned long long q; };
+
+__device__ __forceinline__ bool improves(int mode, int min_inl, int c, unsigned long long q, const BState& st) {
+    if (c < min_inl) return false;
+    return mode == 0 ? (c > st.c) : (q < st.q);
+}
+__device__ __forceinline__ void hyp_best(const int32_t* cnt, const unsigned long long* cost, int mode, int h, int& s_best,
+                                         int& c, unsigned long long& q) {
+    s_best = 0;
+    for (int s = 1; s < 4; ++s)
+        if (mode == 0 ? (cnt[4 * h + s] > cnt[4 * h + s_best]) : (cost[4 * h + s] < cost[4 * h + s_best])) s_best = s;
+    c = cnt[4 * h + s_best]; q = cost[4 * h + s_best];
+}
+__device__ __forceinline__ double ransac_limit(double confidence, int bcnt, int m, int H) {
+    double orat = 1.0 - (double)bcnt / (double)m;
+    if (orat > 0.9) orat = 0.9;
+    double wi = 1.0 - orat;
+    return log(1.0 - confidence) / log(1.0 - wi * wi * wi); // old/ransacLocalization.m:121
+}
+
+struct BestArgs {
+    const int32_t* cnt; const unsigned long long* cost; const double* Rt; int H, M, mode, min_inl;
+    double confidence; double* out; // R_cw(9) t_cw(3) then 5 int32
+};
+
+__global__ __launch_bounds__(64) void k_best(BestArgs a) {
+    const int lane = threadIdx.x;
+    const int per = (a.H + 63) / 64;
+    const int lo = min(lane * per, a.H), hi = min(lo + per, a.H);
+    BState st; st.h = -1; st.s = -1; st.c = 0; st.q = ~0ull;
+    for (int h = lo; h < hi; ++h) {
+        int s, c; unsigned long long q;
+        hyp_best(a.cnt, a.cost, a.mode, h, s, c, q);
+        if (improves(a.mode, a.min_inl, c, q, st)) { st.h = h; st.s = s; st.c = c; st.q = q; }
+    }
+    // inclusive scan over lanes with combine(earlier, later) = later if it strictly improves
+    BState inc = st;
+    for (int d = 1; d < 64; d <<= 1) {
+        BState o;
+        o.h = __shfl_up(inc.h, d, 64); o.s = __shfl_up(inc.s, d, 64); o.c = __shfl_up(inc.c, d, 64);
+        o.q = __shfl_up(inc.q, d, 64);
+        if (lane >= d) {
+            // o = state of the earlier span, inc = state of the later span
+            const bool later_wins = inc.h >= 0 && (o.h < 0 || improves(a.mode, a.min_inl, inc.c, inc.q, o));
+            if (!later_wins) inc = o;
+        }
+    }
+    BState carry;
+    carry.h = __shfl_up(inc.h, 1, 64); carry.s = __shfl_up(inc.s, 1, 64); carry.c = __shfl_up(inc.c, 1, 64);
+    carry.q = __shfl_up(inc.q, 1, 64);
+    if (lane == 0) { carry.h = -1; carry.s = -1; carry.c = 0; carry.q = ~0ull; }
+    // re-walk the chunk with the carried-in state, looking for the adaptive stop
+    BState cur = carry;
+    int stop = 0x7fffffff;
+    if (a.confidence > 0) {
+        double N = ransac_limit(a.confidence, cur.c, a.M, a.H);
+        for (int h = lo; h < hi; ++h) {
+            int s, c; unsigned long long q;
+            hyp_best(a.cnt, a.cost, a.mode, h, s, c, q);
+            if (improves(a.mode, a.min_inl, c, q, cur)) {
+                cur.h = h; cur.s = s; cur.c = c; cur.q = q;
+                N = ransac_limit(a.confidence, cur.c, a.M, a.H);
+            }
+            if (!(N > (double)(h + 2))) { stop = h; break; } // :44 `while num_iterations > i`
+        }
+    } else {
+        cur = inc;
+    }
+    int gstop = stop;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) gstop = min(gstop, __shfl_xor(gstop, d, 64));
+    int owner;
+    if (gstop == 0x7fffffff) owner = 63; // no stop: final state of the last lane (its walk ran to the end)
+    else {
+        const unsigned long long bal = __ballot(stop == gstop);
+        owner = __ffsll((long long)bal) - 1;
+    }
+    if (a.confidence > 0 && gstop == 0x7fffffff) cur = inc; // lanes with empty chunks carry the state through
+    BState fin;
+    fin.h = __shfl(cur.h, owner, 64); fin.s = __shfl(cur.s, owner, 64); fin.c = __shfl(cur.c, owner, 64);
+    fin.q = __shfl(cur.q, owner, 64);
+    if (lane == 0) {
+        int32_t* info = (int32_t*)(a.out + 12);
+        const int used = gstop == 0x7fffffff ? a.H : gstop + 1;
+        if (fin.h >= 0) {
+            const double* p = a.Rt + 48 * (long)fin.h + 12 * fin.s;
+            for (int k = 0; k < 12; ++k) a.out[k] = p[k];
+            info[0] = 0;
+        } else {
+            for (int k = 0; k < 9; ++k) a.out[k] = (k % 4 == 0) ? 1.0 : 0.0;
+            a.out[9] = a.out[10] = a.out[11] = 0.0;
+            info[0] = 2;
+        }
+        info[1] = fin.h; info[2] = fin.s; info[3] = used; info[4] = 0;
+    }
+}
+
+struct InlArgs {
+    const double* xy; vo_strides sxy; const double* X; vo_strides sX; int M; const double* K; double thr2;
+    double* out; uint8_t* inliers;
+};
+__global__ __launch_bounds__(256) void k_inliers(InlArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int32_t* info = (int32_t*)(a.out + 12);
+    bool in = false;
+    if (i < a.M && info[0] == 0) {
+        double R[9], t[3];
+        for (int k = 0; k < 9; ++k) R[k] = a.out[k];
+        for (int k = 0; k < 3; ++k) t[k] = a.out[9 + k];
+        const double e2 = reproj_e2(R, t, a.K[0], a.K[1], a.K[2], a.K[4], a.K[5], a.X[i * a.sX.xi],
+                                    a.X[i * a.sX.xi + a.sX.xc], a.X[i * a.sX.xi + 2 * a.sX.xc], a.xy[i * a.sxy.xi],
+                                    a.xy[i * a.sxy.xi + a.sxy.xc]);
+        in = e2 < a.thr2;
+    }
+    if (i < a.M) a.inliers[i] = in ? 1 : 0;
+    const unsigned long long bal = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&info[4], __popcll(bal));
+}
+
+__global__ __launch_bounds__(64) void k_p3p_batch(const double* P, const double* f, int n, double* poses) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    double Pw[9], fv[9], out[48];
+    for (int k = 0; k < 9; ++k) { Pw[k] = P[9 * (long)i + k]; fv[k] = f[9 * (long)i + k]; }
+    p3p_device(Pw, fv, out);
+    for (int k = 0; k < 48; ++k) poses[48 * (long)i + k] = out[k];
+}
+
+} // namespace
+
+int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int M,
+                     const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
+                     const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers) {
+    const int H = o->num_hyp;
+    if (H < 1 || M < 4 || !(o->max_reproj_err > 0)) { ctx->last_error = "ransac: need num_hyp >= 1, M >= 4, max_reproj_err > 0"; return VO_ERR_BAD_ARG; }
+    if (o->mode != 0 && o->mode != 1) { ctx->last_error = "ransac: mode must be 0 or 1"; return VO_ERR_BAD_ARG; }
+    const double thr2 = o->max_reproj_err * o->max_reproj_err;
+    const double* Rt = w->Rt;
+    if (d_poses_in) Rt = d_poses_in;
+    else {
+        HypArgs h;
+        h.xy = d_xy; h.sxy = sxy; h.X = d_X; h.sX = sX; h.M = M; h.K = d_K; h.H = H; h.seed = o->seed;
+        h.sample_idx = d_sample_idx; h.Rt = w->Rt;
+        hipLaunchKernelGGL(k_hyp, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, h);
+    }
+    ScoreArgs s;
+    s.xy = d_xy; s.sxy = sxy; s.X = d_X; s.sX = sX; s.M = M; s.K = d_K; s.H = H; s.thr2 = thr2; s.Rt = Rt;
+    s.cnt = w->cnt; s.cost = w->cost; s.counters = ctx->d_counters;
+    hipLaunchKernelGGL(k_score, dim3((H + SC_HB - 1) / SC_HB), dim3(256), 0, ctx->stream, s);
+    BestArgs b;
+    b.cnt = w->cnt; b.cost = w->cost; b.Rt = Rt; b.H = H; b.M = M; b.mode = o->mode; b.min_inl = o->min_inliers;
+    b.confidence = o->confidence; b.out = (double*)d_out;
+    hipLaunchKernelGGL(k_best, dim3(1), dim3(64), 0, ctx->stream, b);
+    InlArgs in;
+    in.xy = d_xy; in.sxy = sxy; in.X = d_X; in.sX = sX; in.M = M; in.K = d_K; in.thr2 = thr2; in.out = (double*)d_out;
+    in.inliers = d_inliers;
+    hipLaunchKernelGGL(k_inliers, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, in);
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}
+
+int vo_launch_p3p_batch(vo_ctx* ctx, const double* d_P, const double* d_f, int n, double* d_poses) {
+    if (n <= 0) return VO_OK;
+    hipLaunchKernelGGL(k_p3p_batch, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_P, d_f, n, d_poses);
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}

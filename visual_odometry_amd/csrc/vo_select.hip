@@ -1,0 +1,496 @@
+// vo_select.hip -- candidate keypoint selection: corner response (Shi-Tomasi min-eigen or Harris),
+// 8-neighbour non-max suppression with sub-pixel refinement, distance filter against existing
+// points, uniform (grid) selection; plus the greedy box-suppression selector of old/selectKeypoints.m.
+// Replaces detectMinEigenFeatures + pdist2 + selectUniform as called by
+// modules/selectCandidateKeypoints.m:20-35, and old/harris.m:3-23 / old/selectKeypoints.m:5-14.
+// Normative definitions: oracle/vo_oracle.h N6-N8.  Every decision (threshold, NMS, tie-breaks,
+// distance test, grid cell, ordering) is taken on integers or on IEEE doubles/floats evaluated in
+// the oracle's operation order (this file is compiled with -ffp-contract=off), so the selected
+// indices are bit-exact.
+//
+// Bound: image-wide stencils are HBM/L2 streaming (read 1 B/px, write 8 B/px response, re-read
+// 8 B/px for NMS); the distance filter is a tiled all-pairs test in LDS (VALU bound).
+#include "vo_common.h"
+
+namespace {
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+constexpr int RS_TU = 64, RS_TV = 16; // response tile
+
+struct RespArgs {
+    const uint8_t* img;
+    int nu, nv, r, scorer;
+    double kappa;
+    int32_t w[16];
+    double* resp;
+    unsigned long long* maxbits;
+};
+
+// One block = one RS_TU x RS_TV tile.  LDS: uint8 tile with halo r+1; int32 products on the tile
+// with halo r; int64 horizontal sums.  MINEIGEN uses replicate borders at every stage (N6), HARRIS
+// only produces values where the whole support is inside the image (old/harris.m 'valid').
+__global__ __launch_bounds__(256) void k_response(RespArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int r = a.r, nu = a.nu, nv = a.nv;
+    const int SW = RS_TU + 2 * r + 2, SH = RS_TV + 2 * r + 2; // staged bytes
+    const int PW = RS_TU + 2 * r, PH = RS_TV + 2 * r;         // products
+    uint8_t* S = smem;
+    int32_t* pa = (int32_t*)(smem + ((SW * SH + 15) & ~15));
+    int32_t* pb = pa + PW * PH;
+    int32_t* pc = pb + PW * PH;
+    long long* ha = (long long*)(pc + PW * PH + ((PW * PH) & 1));
+    long long* hb = ha + RS_TU * PH;
+    long long* hc = hb + RS_TU * PH;
+    const int u0 = blockIdx.x * RS_TU, v0 = blockIdx.y * RS_TV;
+    const int su0 = u0 - r - 1, sv0 = v0 - r - 1;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < SW * SH; c += 256) {
+        int y = c / SW, x = c - y * SW;
+        S[c] = a.img[(long)clampi(sv0 + y, 0, nv - 1) * nu + clampi(su0 + x, 0, nu - 1)];
+    }
+    __syncthreads();
+#define PX(cu, cv) ((int)S[((cv) - sv0) * SW + ((cu) - su0)])
+    for (int c = tid; c < PW * PH; c += 256) {
+        int y = c / PW, x = c - y * PW;
+        int ru = u0 - r + x, rv = v0 - r + y;
+        int va, vb, vc;
+        if (a.scorer == VO_SCORER_MINEIGEN) {
+            int cu = clampi(ru, 0, nu - 1), cv = clampi(rv, 0, nv - 1);
+            int du = PX(clampi(cu + 1, 0, nu - 1), cv) - PX(clampi(cu - 1, 0, nu - 1), cv);
+            int dv = PX(cu, clampi(cv + 1, 0, nv - 1)) - PX(cu, clampi(cv - 1, 0, nv - 1));
+            va = du * du; vb = du * dv; vc = dv * dv;
+        } else {
+            // old/harris.m:3-10, centre (ru, rv); zero where the 3x3 support leaves the image
+            if (ru >= 1 && ru <= nu - 2 && rv >= 1 && rv <= nv - 2) {
+                int ix = (PX(ru - 1, rv - 1) + 2 * PX(ru - 1, rv) + PX(ru - 1, rv + 1)) -
+                         (PX(ru + 1, rv - 1) + 2 * PX(ru + 1, rv) + PX(ru + 1, rv + 1));
+                int iy = (PX(ru - 1, rv - 1) + 2 * PX(ru, rv - 1) + PX(ru + 1, rv - 1)) -
+                         (PX(ru - 1, rv + 1) + 2 * PX(ru, rv + 1) + PX(ru + 1, rv + 1));
+                va = ix * ix; vb = ix * iy; vc = iy * iy;
+            } else { va = vb = vc = 0; }
+        }
+        pa[c] = va; pb[c] = vb; pc[c] = vc;
+    }
+#undef PX
+    __syncthreads();
+    // horizontal pass.  MINEIGEN: index clamp(u+k) of the product arrays (replicate the PRODUCTS).
+    for (int c = tid; c < RS_TU * PH; c += 256) {
+        int y = c / RS_TU, x = c - y * RS_TU;
+        long long sa = 0, sb = 0, sc = 0;
+        for (int k = -r; k <= r; ++k) {
+            int xx;
+            if (a.scorer == VO_SCORER_MINEIGEN) xx = clampi(u0 + x + k, 0, nu - 1) - (u0 - r);
+            else xx = x + r + k;
+            xx = clampi(xx, 0, PW - 1);
+            long long w = a.w[k + r];
+            sa += w * pa[y * PW + xx]; sb += w * pb[y * PW + xx]; sc += w * pc[y * PW + xx];
+        }
+        ha[c] = sa; hb[c] = sb; hc[c] = sc;
+    }
+    __syncthreads();
+    double bmax = 0.0;
+    for (int c = tid; c < RS_TU * RS_TV; c += 256) {
+        int y = c / RS_TU, x = c - y * RS_TU;
+        int u = u0 + x, v = v0 + y;
+        if (u >= nu || v >= nv) continue;
+        long long sa = 0, sb = 0, sc = 0;
+        for (int k = -r; k <= r; ++k) {
+            int yy;
+            if (a.scorer == VO_SCORER_MINEIGEN) yy = clampi(v + k, 0, nv - 1) - (v0 - r);
+            else yy = y + r + k;
+            yy = clampi(yy, 0, PH - 1);
+            long long w = a.w[k + r];
+            sa += w * ha[yy * RS_TU + x]; sb += w * hb[yy * RS_TU + x]; sc += w * hc[yy * RS_TU + x];
+        }
+        double out;
+        if (a.scorer == VO_SCORER_MINEIGEN) {
+            double A = (double)sa, B = (double)sb, C = (double)sc;
+            double dif = A - C;
+            double rad = dif * dif + 4.0 * (B * B);
+            double lam = 0.5 * ((A + C) - sqrt(rad));
+            if (lam < 0.0) lam = 0.0;
+            out = lam * (1.0 / 67108864.0);
+        } else {
+            out = 0.0;
+            if (u >= 1 + r && u < nu - 1 - r && v >= 1 + r && v < nv - 1 - r) {
+                double sxx = (double)sa, sxy = (double)sb, syy = (double)sc;
+                double tr = sxx + syy;
+                double s = (sxx * syy - sxy * sxy) - a.kappa * (tr * tr);
+                if (s < 0) s = 0;
+                out = s;
+            }
+        }
+        a.resp[(long)v * nu + u] = out;
+        if (out > bmax) bmax = out;
+    }
+    if (a.maxbits) {
+        // non-negative doubles order like their bit patterns
+        unsigned long long bits = (unsigned long long)__double_as_longlong(bmax);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            unsigned long long o = __shfl_xor(bits, s, 64);
+            bits = o > bits ? o : bits;
+        }
+        if ((tid & 63) == 0 && bits) atomicMax(a.maxbits, bits);
+    }
+}
+
+// ---- N7 detection.  One block = 1024 consecutive linear indices; pass 0 counts, pass 1 writes.
+constexpr int DT_BLOCK = 1024;
+
+__device__ __forceinline__ bool is_corner(const double* __restrict__ resp, int nu, int nv, long i, double thr) {
+    const int v = (int)(i / nu), u = (int)(i - (long)v * nu);
+    if (u < 1 || u >= nu - 1 || v < 1 || v >= nv - 1) return false;
+    const double r = resp[i];
+    if (!(r > thr)) return false;
+#pragma unroll
+    for (int dv = -1; dv <= 1; ++dv)
+#pragma unroll
+        for (int du = -1; du <= 1; ++du) {
+            if (!du && !dv) continue;
+            const long j = i + (long)dv * nu + du;
+            const double q = resp[j];
+            if (q > r || (q == r && j < i)) return false;
+        }
+    return true;
+}
+
+__global__ __launch_bounds__(DT_BLOCK) void k_detect(const double* __restrict__ resp, int nu, int nv,
+                                                      const unsigned long long* __restrict__ maxbits,
+                                                      double min_quality, int pass, int32_t* blk_counts,
+                                                      const int32_t* __restrict__ blk_offs, int cap,
+                                                      int32_t* lin, float* lu, float* lv, double* metric) {
+    __shared__ int wave_cnt[DT_BLOCK / 64];
+    const long n = (long)nu * nv;
+    const long i = (long)blockIdx.x * DT_BLOCK + threadIdx.x;
+    const double thr = min_quality * __longlong_as_double((long long)*maxbits);
+    const bool c = i < n && is_corner(resp, nu, nv, i, thr);
+    const unsigned long long bal = __ballot(c);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wid] = __popcll(bal);
+    __syncthreads();
+    if (pass == 0) {
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < DT_BLOCK / 64; ++w) t += wave_cnt[w];
+            blk_counts[blockIdx.x] = t;
+        }
+        return;
+    }
+    if (!c) return;
+    int pos = blk_offs[blockIdx.x];
+    for (int w = 0; w < wid; ++w) pos += wave_cnt[w];
+    pos += __popcll(bal & ((1ull << lane) - 1ull));
+    if (pos >= cap) return;
+    const int v = (int)(i / nu), u = (int)(i - (long)v * nu);
+    const double r = resp[i];
+    const double rum = resp[i - 1], rup = resp[i + 1], rvm = resp[i - nu], rvp = resp[i + nu];
+    const double cuu = (rup - 2.0 * r) + rum, cvv = (rvp - 2.0 * r) + rvm;
+    double ou = 0, ov = 0;
+    if (cuu < 0) { ou = -0.5 * (rup - rum) / cuu; if (ou > 0.5) ou = 0.5; if (ou < -0.5) ou = -0.5; }
+    if (cvv < 0) { ov = -0.5 * (rvp - rvm) / cvv; if (ov > 0.5) ov = 0.5; if (ov < -0.5) ov = -0.5; }
+    lin[pos] = (int32_t)i;
+    lu[pos] = (float)((double)u + ou);
+    lv[pos] = (float)((double)v + ov);
+    metric[pos] = r;
+}
+
+// exclusive scan of the per-block counts (single block), total -> *m0 (clamped to cap)
+__global__ __launch_bounds__(1024) void k_scan_counts(const int32_t* __restrict__ counts, int nblk, int32_t* offs,
+                                                       int32_t* m0, int cap) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (nblk + 1023) / 1024;
+    int s = 0;
+    for (int k = 0; k < per; ++k) { int i = t * per + k; if (i < nblk) s += counts[i]; }
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        int x = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int k = 0; k < per; ++k) { int i = t * per + k; if (i < nblk) { offs[i] = run; run += counts[i]; } }
+    if (t == 1023) *m0 = part[t] < cap ? part[t] : cap;
+}
+
+// ---- N8 distance filter: keep[i] = no existing point with d2 < thr_d2 (thr_d2 = smallest float
+// whose correctly rounded sqrtf reaches min_distance, computed on the host)
+__global__ __launch_bounds__(256) void k_distance(const float* __restrict__ cu, const float* __restrict__ cv,
+                                                   const int32_t* __restrict__ m0, const float* __restrict__ eu,
+                                                   const float* __restrict__ ev, int ne, float thr_d2, uint8_t* keep) {
+    __shared__ float su[1024], sv[1024];
+    const int m = *m0;
+    if ((int)(blockIdx.x * 256) >= m) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool act = i < m;
+    const float pu = act ? cu[i] : 0.0f, pv = act ? cv[i] : 0.0f;
+    bool k = true;
+    for (int base = 0; base < ne; base += 1024) {
+        const int cnt = min(1024, ne - base);
+        __syncthreads();
+        for (int j = threadIdx.x; j < cnt; j += 256) { su[j] = eu[base + j]; sv[j] = ev[base + j]; }
+        __syncthreads();
+        if (k && act) {
+            for (int j = 0; j < cnt; ++j) {
+                const float dx = pu - su[j], dy = pv - sv[j];
+                const float d2 = dx * dx + dy * dy;
+                if (d2 < thr_d2) { k = false; break; }
+            }
+        }
+    }
+    if (act) keep[i] = k ? 1 : 0;
+}
+
+// ---- N8 selectUniform + ordered output.  Single block; cell tables in global scratch.
+struct UniArgs {
+    const float *cu, *cv; const double* metric; const int32_t* lin; const uint8_t* keep; uint8_t* sel;
+    const int32_t* m0; int n_keep, nu, nv, u_is_rows;
+    unsigned long long* cell_key; int32_t* cell_idx;
+    float *out_u, *out_v; int32_t* out_lin; double* out_metric; int32_t* out_count;
+};
+
+__global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
+    __shared__ int s_cnt[16];
+    __shared__ int s_remaining, s_selected, s_round_sel;
+    const int t = threadIdx.x, m = *a.m0;
+    int loc = 0;
+    for (int i = t; i < m; i += 1024) { a.sel[i] = 0; loc += a.keep[i] ? 1 : 0; }
+    if (t == 0) { s_remaining = 0; s_selected = 0; }
+    __syncthreads();
+    if (loc) atomicAdd(&s_remaining, loc);
+    __syncthreads();
+    const long H = a.u_is_rows ? a.nu : a.nv, W = a.u_is_rows ? a.nv : a.nu;
+    while (true) {
+        const int selected = s_selected, remaining = s_remaining;
+        if (!(selected < a.n_keep && remaining > 0)) break;
+        const long want = a.n_keep - selected;
+        long x = (want * H) / W, h = 0;
+        while ((h + 1) * (h + 1) <= x) ++h;
+        if (h < 1) h = 1;
+        if (h > want) h = want;
+        long w = (h * W) / H; if (w < 1) w = 1; if (h * w > want) w = want / h;
+        const int cells_u = (int)(a.u_is_rows ? h : w), cells_v = (int)(a.u_is_rows ? w : h);
+        const int nc = cells_u * cells_v;
+        for (int k = t; k < nc; k += 1024) { a.cell_key[k] = 0ull; a.cell_idx[k] = 0x7fffffff; }
+        if (t == 0) s_round_sel = 0;
+        __syncthreads();
+        // phase 1: per-cell maximum metric (metric > 0 for every corner, so key 0 = empty)
+        for (int i = t; i < m; i += 1024) {
+            if (!a.keep[i] || a.sel[i]) continue;
+            int bu = (int)floor(((double)a.cu[i] * (double)cells_u) / (double)a.nu);
+            int bv = (int)floor(((double)a.cv[i] * (double)cells_v) / (double)a.nv);
+            bu = clampi(bu, 0, cells_u - 1); bv = clampi(bv, 0, cells_v - 1);
+            // +1 so that a zero metric still differs from "empty"
+            atomicMax(&a.cell_key[bv * cells_u + bu], (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull);
+        }
+        __threadfence_block();
+        __syncthreads();
+        // phase 2: lowest index among the maxima
+        for (int i = t; i < m; i += 1024) {
+            if (!a.keep[i] || a.sel[i]) continue;
+            int bu = (int)floor(((double)a.cu[i] * (double)cells_u) / (double)a.nu);
+            int bv = (int)floor(((double)a.cv[i] * (double)cells_v) / (double)a.nv);
+            bu = clampi(bu, 0, cells_u - 1); bv = clampi(bv, 0, cells_v - 1);
+            const int cell = bv * cells_u + bu;
+            const unsigned long long key = (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull;
+            if (__hip_atomic_load(&a.cell_key[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key)
+                atomicMin(&a.cell_idx[cell], i);
+        }
+        __threadfence_block();
+        __syncthreads();
+        int got = 0;
+        for (int k = t; k < nc; k += 1024) {
+            const int idx = __hip_atomic_load(&a.cell_idx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (idx != 0x7fffffff) { a.sel[idx] = 1; ++got; }
+        }
+        if (got) atomicAdd(&s_round_sel, got);
+        __syncthreads();
+        if (t == 0) { s_selected += s_round_sel; s_remaining -= s_round_sel; }
+        __syncthreads();
+    }
+    // ordered compaction of sel[] (ascending corner index)
+    int base = 0;
+    const int lane = t & 63, wid = t >> 6;
+    for (int start = 0; start < m; start += 1024) {
+        const int i = start + t;
+        const bool s = i < m && a.sel[i];
+        const unsigned long long bal = __ballot(s);
+        if (lane == 0) s_cnt[wid] = __popcll(bal);
+        __syncthreads();
+        int pos = base, tot = 0;
+        for (int w2 = 0; w2 < 16; ++w2) { if (w2 < wid) pos += s_cnt[w2]; tot += s_cnt[w2]; }
+        pos += __popcll(bal & ((1ull << lane) - 1ull));
+        if (s) {
+            a.out_u[pos] = a.cu[i]; a.out_v[pos] = a.cv[i];
+            if (a.out_lin) a.out_lin[pos] = a.lin[i];
+            if (a.out_metric) a.out_metric[pos] = a.metric[i];
+        }
+        base += tot;
+        __syncthreads();
+    }
+    if (t == 0) *a.out_count = base;
+}
+
+// ---- old/selectKeypoints.m:5-14 greedy selection: per iteration, block partial arg-max (first
+// maximum in linear order), then one block reduces the partials, records the pick and zeroes the
+// (2r+1)^2 box.
+constexpr int GR_BLOCK = 256, GR_PER = 16;
+__global__ __launch_bounds__(GR_BLOCK) void k_greedy_partial(const double* __restrict__ sc, long n,
+                                                             unsigned long long* pv, int32_t* pi) {
+    __shared__ unsigned long long sv[GR_BLOCK / 64];
+    __shared__ int si[GR_BLOCK / 64];
+    const long base = (long)blockIdx.x * GR_BLOCK * GR_PER;
+    unsigned long long bv = 0; int bi = 0x7fffffff;
+    for (int k = 0; k < GR_PER; ++k) {
+        const long i = base + (long)k * GR_BLOCK + threadIdx.x;
+        if (i < n) {
+            const double d = sc[i];
+            const unsigned long long b = d > 0.0 ? (unsigned long long)__double_as_longlong(d) : 0ull;
+            if (b > bv) { bv = b; bi = (int)i; } // ascending i per thread keeps the first maximum
+        }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long ov = __shfl_xor(bv, s, 64);
+        const int oi = __shfl_xor(bi, s, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < GR_BLOCK / 64; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        pv[blockIdx.x] = bv; pi[blockIdx.x] = bi;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_greedy_pick(double* sc, int nu, int nv, const unsigned long long* pv,
+                                                      const int32_t* pi, int nblk, int r, int it, int32_t* out_uv) {
+    __shared__ unsigned long long sv[16];
+    __shared__ int si[16];
+    __shared__ int s_best;
+    unsigned long long bv = 0; int bi = 0x7fffffff;
+    for (int k = threadIdx.x; k < nblk; k += 1024) {
+        const unsigned long long v = pv[k]; const int i = pi[k];
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long ov = __shfl_xor(bv, s, 64);
+        const int oi = __shfl_xor(bi, s, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        // all-zero image: MATLAB's max() returns the first element of the zero-padded array
+        int ku, kv;
+        if (bv == 0ull) { ku = -r; kv = -r; s_best = -1; }
+        else { kv = bi / nu; ku = bi - kv * nu; s_best = bi; }
+        out_uv[2 * it] = ku; out_uv[2 * it + 1] = kv;
+    }
+    __syncthreads();
+    const int b = s_best;
+    int ku, kv;
+    if (b < 0) { ku = -r; kv = -r; } else { kv = b / nu; ku = b - kv * nu; }
+    const int side = 2 * r + 1;
+    for (int c = threadIdx.x; c < side * side; c += 1024) {
+        const int dv = c / side - r, du = c % side - r;
+        const int x = ku + du, y = kv + dv;
+        if (x >= 0 && x < nu && y >= 0 && y < nv) sc[(long)y * nu + x] = 0.0;
+    }
+}
+
+} // namespace
+
+static void gauss_weights_host(int fs, int32_t* w) { // N6, identical to oracle/select.c
+    int r = fs / 2;
+    double s = (double)fs / 3.0, sum = 0, g[64];
+    for (int k = -r; k <= r; ++k) { g[k + r] = exp(-(double)(k * k) / (2.0 * s * s)); sum += g[k + r]; }
+    for (int k = 0; k < fs; ++k) w[k] = (int32_t)lround(4096.0 * g[k] / sum);
+}
+
+int vo_launch_response(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int scorer, int fs, double kappa,
+                       double* d_resp, unsigned long long* d_maxbits) {
+    if (fs < 1 || fs > 15 || !(fs & 1)) { ctx->last_error = "select: filter_size must be odd in [1,15]"; return VO_ERR_BAD_ARG; }
+    if (scorer != VO_SCORER_MINEIGEN && scorer != VO_SCORER_HARRIS) { ctx->last_error = "select: unknown scorer"; return VO_ERR_BAD_ARG; }
+    if (nu < 3 || nv < 3) { ctx->last_error = "select: image smaller than 3x3"; return VO_ERR_BAD_ARG; }
+    RespArgs a;
+    a.img = d_img; a.nu = nu; a.nv = nv; a.r = fs / 2; a.scorer = scorer; a.kappa = kappa;
+    a.resp = d_resp; a.maxbits = d_maxbits;
+    for (int k = 0; k < 16; ++k) a.w[k] = 1;
+    if (scorer == VO_SCORER_MINEIGEN) gauss_weights_host(fs, a.w);
+    const int r = a.r;
+    const int SW = RS_TU + 2 * r + 2, SH = RS_TV + 2 * r + 2, PW = RS_TU + 2 * r, PH = RS_TV + 2 * r;
+    size_t lds = ((size_t)(SW * SH + 15) & ~(size_t)15) + sizeof(int32_t) * (3 * (size_t)PW * PH + ((PW * PH) & 1)) +
+                 sizeof(long long) * 3 * (size_t)RS_TU * PH;
+    if (d_maxbits) VO_HIP_CHECK(ctx, hipMemsetAsync(d_maxbits, 0, sizeof(unsigned long long), ctx->stream));
+    dim3 grid((nu + RS_TU - 1) / RS_TU, (nv + RS_TV - 1) / RS_TV);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_response, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_response, grid, dim3(256), lds, ctx->stream, a);
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}
+
+// smallest float x with sqrtf(x) >= d (sqrtf is correctly rounded and monotone on the host)
+static float d2_threshold(float d) {
+    if (!(d > 0.0f)) return 0.0f;
+    float x = d * d;
+    while (sqrtf(x) >= d && x > 0.0f) x = nextafterf(x, 0.0f);
+    while (sqrtf(x) < d) x = nextafterf(x, INFINITY);
+    return x;
+}
+
+int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is_rows, const float* d_eu,
+                     const float* d_ev, int n_exist, const vo_sel_opts* o, vo_sel_work* w, float* d_out_u,
+                     float* d_out_v, int32_t* d_out_lin, double* d_out_metric, int32_t* d_out_count) {
+    if (o->keep < 0 || n_exist < 0) { ctx->last_error = "select: negative count"; return VO_ERR_BAD_ARG; }
+    int rc = vo_launch_response(ctx, d_img, nu, nv, o->scorer, o->filter_size, o->kappa, w->resp, w->maxbits);
+    if (rc) return rc;
+    const long n = (long)nu * nv;
+    const int nblk = (int)((n + DT_BLOCK - 1) / DT_BLOCK);
+    if (nblk > w->nblk) { ctx->last_error = "select: scratch too small"; return VO_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, ctx->stream, w->resp, nu, nv, w->maxbits,
+                       o->min_quality, 0, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, w->blk_counts, nblk, w->blk_offs, w->m0, w->cap);
+    hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, ctx->stream, w->resp, nu, nv, w->maxbits,
+                       o->min_quality, 1, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric);
+    const int dblk = (w->cap + 255) / 256;
+    hipLaunchKernelGGL(k_distance, dim3(dblk), dim3(256), 0, ctx->stream, w->lu, w->lv, w->m0, d_eu, d_ev, n_exist,
+                       d2_threshold((float)o->min_distance), w->keep);
+    UniArgs a;
+    a.cu = w->lu; a.cv = w->lv; a.metric = w->metric; a.lin = w->lin; a.keep = w->keep; a.sel = w->sel; a.m0 = w->m0;
+    a.n_keep = o->keep; a.nu = nu; a.nv = nv; a.u_is_rows = u_is_rows;
+    a.cell_key = w->cell_key; a.cell_idx = w->cell_idx;
+    a.out_u = d_out_u; a.out_v = d_out_v; a.out_lin = d_out_lin; a.out_metric = d_out_metric; a.out_count = d_out_count;
+    hipLaunchKernelGGL(k_uniform, dim3(1), dim3(1024), 0, ctx->stream, a);
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}
+
+int vo_greedy_num_blocks(long n) { return (int)((n + (long)GR_BLOCK * GR_PER - 1) / ((long)GR_BLOCK * GR_PER)); }
+
+int vo_launch_greedy(vo_ctx* ctx, double* d_scores_work, int nu, int nv, int num, int r, int32_t* d_out_uv,
+                     unsigned long long* d_tmp) {
+    if (num < 0 || r < 0) { ctx->last_error = "greedy: negative argument"; return VO_ERR_BAD_ARG; }
+    const long n = (long)nu * nv;
+    const int nblk = vo_greedy_num_blocks(n);
+    unsigned long long* pv = d_tmp;
+    int32_t* pi = (int32_t*)(d_tmp + nblk);
+    for (int it = 0; it < num; ++it) {
+        hipLaunchKernelGGL(k_greedy_partial, dim3(nblk), dim3(GR_BLOCK), 0, ctx->stream, d_scores_work, n, pv, pi);
+        hipLaunchKernelGGL(k_greedy_pick, dim3(1), dim3(1024), 0, ctx->stream, d_scores_work, nu, nv, pv, pi, nblk, r, it, d_out_uv);
+    }
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}

@@ -1,0 +1,120 @@
+"""Device-resident frame workload over the vo_dev_* entry points (inputs and outputs stay in HBM).
+
+One `step` is the hot path of one VO frame (modules/VisualOdometry.m:264-346) on synthetic inputs:
+pyramid build of the new frame (the previous frame's pyramid is reused from its slot), KLT track of
+the landmark keypoints (:278) and of the candidate keypoints (:71), P3P-RANSAC pose (:285),
+batched candidate triangulation + angle + cheirality (:87-113) and candidate selection (:330).
+torch is used for device memory only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, synth
+from ._lib import RansacOpts, SelOpts
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class FrameWorkload:
+    def __init__(self, ctx, n_landmarks, n_candidates, nv=376, nu=1241, n_frames=16, num_hyp=2000, levels=4,
+                 block=41, max_iters=50, eps=0.01, max_bidir=2.0, keep=100, seed=1023, device=None):
+        self.ctx = ctx
+        self.dev = torch.device("cuda", ctx.device if device is None else device)
+        self.nu, self.nv, self.levels, self.block = nu, nv, levels, block
+        self.max_iters, self.eps, self.max_bidir = max_iters, eps, max_bidir
+        self.nl, self.nc = int(n_landmarks), int(n_candidates)
+        frames, self.warps = synth.frame_sequence(n_frames + 1, nv, nu, seed=seed)
+        self.frames = [torch.from_numpy(f).to(self.dev) for f in frames]          # uint8, resident
+        self.n_frames = n_frames
+        f64 = dict(dtype=torch.float64, device=self.dev)
+
+        def pts(n, sd):
+            u, v = synth.keypoints(n, nv, nu, seed=sd)
+            return torch.from_numpy(np.stack([u, v])).to(self.dev).contiguous()       # SoA 2 x n
+
+        self.pl, self.pc = pts(self.nl, seed + 1024), pts(self.nc, seed + 2048)
+        self.ql, self.qc = torch.empty_like(self.pl), torch.empty_like(self.pc)
+        self.vl = torch.empty(self.nl, dtype=torch.uint8, device=self.dev)
+        self.vc = torch.empty(self.nc, dtype=torch.uint8, device=self.dev)
+        self.sl = torch.empty(self.nl, dtype=torch.float32, device=self.dev)
+        self.sc = torch.empty(self.nc, dtype=torch.float32, device=self.dev)
+        # pose step: landmarks + observations
+        xy, X, *_ = synth.pnp_scene(self.nl, seed=seed + 3072, nv=nv, nu=nu)
+        self.rs_xy = torch.from_numpy(xy).to(self.dev); self.rs_X = torch.from_numpy(X).to(self.dev)
+        self.K = torch.from_numpy(np.ascontiguousarray(synth.KITTI_K)).to(self.dev)
+        self.rs_out = torch.zeros(16, **f64)
+        self.rs_inl = torch.empty(self.nl, dtype=torch.uint8, device=self.dev)
+        self.rs_opts = RansacOpts(int(num_hyp), 2.0, 0.0, seed, 1, 4)
+        # triangulation: candidates observed first from one of 10 poses (pose table + index)
+        xy0, xy1, poses0, pose1, _ = synth.triangulation_scene(self.nc, seed=seed + 4096, nv=nv, nu=nu)
+        uniq, idx = np.unique(poses0.reshape(len(poses0), -1), axis=0, return_inverse=True)
+        self.tr_xy0 = torch.from_numpy(xy0).to(self.dev); self.tr_xy1 = torch.from_numpy(xy1).to(self.dev)
+        self.tr_poses = torch.from_numpy(np.ascontiguousarray(uniq)).to(self.dev)
+        self.tr_idx = torch.from_numpy(idx.astype(np.int32)).to(self.dev)
+        self.tr_pose1 = torch.from_numpy(np.ascontiguousarray(pose1)).to(self.dev)
+        self.tr_X = torch.empty((self.nc, 3), **f64)
+        self.tr_rep = torch.empty(self.nc, **f64); self.tr_ang = torch.empty(self.nc, **f64)
+        self.tr_val = torch.empty(self.nc, dtype=torch.uint8, device=self.dev)
+        # selection against every tracked point
+        ex = torch.cat([self.pl, self.pc], 1).to(torch.float32).contiguous()
+        self.ex = ex; self.n_exist = ex.shape[1]
+        self.sel_opts = SelOpts(7.0, 0.001, 5, int(keep), _lib.SCORER_MINEIGEN, 0.08)
+        self.sel_u = torch.empty(max(keep, 1), dtype=torch.float32, device=self.dev)
+        self.sel_v = torch.empty_like(self.sel_u)
+        self.sel_lin = torch.empty(max(keep, 1), dtype=torch.int32, device=self.dev)
+        self.sel_cnt = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        torch.cuda.synchronize(self.dev)
+        self.k = 0
+        self.build(0, 0)
+
+    # ---- single stages (asynchronous on the ctx stream) ----
+    def build(self, slot, frame):
+        self.ctx.call("vo_dev_frame_build", slot, _p(self.frames[frame]), self.nu, self.nv, self.levels)
+
+    def track(self, a, b, p, q, valid, score):
+        n = p.shape[1]
+        self.ctx.call("vo_dev_klt_track", a, b, _p(p[0]), _p(p[1]), n, self.block, self.block, self.max_iters,
+                      C.c_double(self.eps), C.c_double(self.max_bidir), _p(q[0]), _p(q[1]), _p(valid), _p(score), None)
+
+    def track_landmarks(self, a, b):
+        self.track(a, b, self.pl, self.ql, self.vl, self.sl)
+
+    def track_candidates(self, a, b):
+        self.track(a, b, self.pc, self.qc, self.vc, self.sc)
+
+    def pose(self):
+        self.ctx.call("vo_dev_p3p_ransac", _p(self.rs_xy), _p(self.rs_X), self.nl, _p(self.K), C.byref(self.rs_opts),
+                      None, None, _p(self.rs_out), _p(self.rs_inl))
+
+    def triangulate(self):
+        self.ctx.call("vo_dev_triangulate", _p(self.tr_xy0), _p(self.tr_xy1), _p(self.tr_poses),
+                      self.tr_poses.shape[0], _p(self.tr_idx), self.nc, _p(self.tr_pose1), _p(self.K), _p(self.tr_X),
+                      _p(self.tr_rep), _p(self.tr_ang), _p(self.tr_val))
+
+    def select(self, frame):
+        self.ctx.call("vo_dev_select_candidates", _p(self.frames[frame]), self.nu, self.nv, 0, _p(self.ex[0]),
+                      _p(self.ex[1]), self.n_exist, C.byref(self.sel_opts), _p(self.sel_u), _p(self.sel_v),
+                      _p(self.sel_lin), None, _p(self.sel_cnt))
+
+    def step(self):
+        """frame k (slot k%2, already built) -> frame k+1."""
+        k = self.k
+        a, b = k % 2, (k + 1) % 2
+        nxt = (k % self.n_frames) + 1
+        self.build(b, nxt)
+        self.track_landmarks(a, b)
+        if self.nl >= 4:
+            self.pose()
+        self.track_candidates(a, b)
+        self.triangulate()
+        self.select(nxt)
+        self.k += 1
+        if self.k % self.n_frames == 0:       # loop the sequence: rebuild frame 0 as "previous"
+            self.build(self.k % 2, 0)
+
+    def sync(self):
+        self.ctx.sync()

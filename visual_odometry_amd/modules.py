@@ -1,0 +1,240 @@
+"""Host-side mirror of the reference's operator interface for the hot path (same names, argument
+meaning and error behaviour as the MATLAB originals), over the C ABI of libvo_hip.so.
+
+MATLAB/Octave are absent from the build image, so the host side above the C ABI is written in Python
+and mirrors the MATLAB signatures; the MEX gateways a maintainer would compile live in `mex/` and the
+MATLAB replacement files in `matlab/`.  Conventions follow MATLAB: points are
+N x 2 `[x y]` with 1-based pixel coordinates, poses are 4 x 3 `[R_WC; t_WC]`
+(modules/VisualOdometry.m:318) and `cameraParams.IntrinsicMatrix` is K^T
+(utils/dataLoaderKitti.m:50-53).  A Fortran-ordered image is passed through as MATLAB memory.
+
+    KLTTracker                  modules/KLTTracker.m:1-43
+    selectCandidateKeypoints    modules/selectCandidateKeypoints.m:1-36
+    candidateTriangulation      modules/candidateTriangulation.m:1-117 (free function)
+    VisualOdometry              modules/VisualOdometry.m (processFrame :264-346, candidateTriangulation :63-151)
+    estimateWorldCameraPose     the toolbox call of modules/VisualOdometry.m:285-289
+    calculateAngleDeg           utils/calculateAngleDeg.m:1-11
+    isInFrontOfCamera           modules/isInFrontOfCamera.m:1-12
+    harris, selectKeypoints, p3p  old/harris.m, old/selectKeypoints.m, old/p3p.m
+"""
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import ops
+
+
+class CameraParams(SimpleNamespace):
+    """Stand-in for MATLAB's cameraParameters: `.IntrinsicMatrix` = K^T (utils/dataLoaderKitti.m:53)."""
+
+    def __init__(self, K):
+        K = np.asarray(K, np.float64)
+        super().__init__(IntrinsicMatrix=K.T.copy(), K=K.copy())
+
+
+class KLTTracker:
+    """modules/KLTTracker.m:1-43.  Options and defaults of :11-14."""
+
+    def __init__(self, NumPyramidLevels=4, MaxBidirectionalError=2, BlockSize=(41, 41), MaxIterations=50):
+        bs = tuple(int(b) for b in np.ravel(BlockSize))
+        if len(bs) != 2 or any(b < 5 or b % 2 == 0 for b in bs):
+            # vision.PointTracker: "BlockSize must be odd integers >= 5"
+            raise ValueError("BlockSize must be two odd integers >= 5")
+        if int(NumPyramidLevels) < 1 or int(MaxIterations) < 1:
+            raise ValueError("NumPyramidLevels and MaxIterations must be >= 1")
+        self.NumPyramidLevels = int(NumPyramidLevels)
+        self.MaxBidirectionalError = float(MaxBidirectionalError)
+        self.BlockSize = bs
+        self.MaxIterations = int(MaxIterations)
+
+    def track(self, img1, img2, img1_pts):
+        """[points, validity, scores] = track(obj, img1, img2, img1_pts)  (modules/KLTTracker.m:22-41).
+        Empty input returns typed empties (:33-36)."""
+        return ops.klt_track(img1, img2, img1_pts, levels=self.NumPyramidLevels,
+                             max_bidir_err=self.MaxBidirectionalError, block=self.BlockSize,
+                             max_iters=self.MaxIterations)
+
+
+def selectCandidateKeypoints(img, curr_kps, MinDistance=20, MinQuality=0.01, FilterSize=3, CandidatesToKeep=200,
+                             Scorer="mineigen"):
+    """modules/selectCandidateKeypoints.m:1-36 (defaults :13-16).  As in the reference, FilterSize is
+    accepted but NOT forwarded to the detector (:20), which runs at the toolbox default of 5."""
+    del FilterSize
+    return ops.select_candidates(img, curr_kps, min_distance=MinDistance, min_quality=MinQuality, filter_size=5,
+                                 keep=int(CandidatesToKeep), scorer=Scorer)
+
+
+def calculateAngleDeg(landmark, cam_pose0, cam_pose1):
+    """utils/calculateAngleDeg.m:1-11 (1 x 3 landmark -> scalar; N x 3 -> N)."""
+    lm = np.asarray(landmark, np.float64)
+    a = ops.angle_deg(lm.reshape(-1, 3), cam_pose0, cam_pose1)
+    return float(a[0]) if lm.ndim == 1 or lm.shape[0] == 1 else a
+
+
+def isInFrontOfCamera(camMat, points3d):
+    """modules/isInFrontOfCamera.m:1-12: camMat 4 x 3, points N x 3 -> N logical."""
+    return ops.in_front(camMat, points3d)
+
+
+def estimateWorldCameraPose(imagePoints, worldPoints, cameraParams, MaxNumTrials=1000, Confidence=99,
+                            MaxReprojectionError=1, Seed=1023, SampleIdx=None):
+    """The pose step's toolbox call (modules/VisualOdometry.m:285-289): P3P inside MSAC.
+    Returns (worldOrientation 3x3, worldLocation 1x3, inlierIdx, status) with status 0 ok /
+    1 not enough points / 2 not enough inliers.  Confidence is a percentage, as in MATLAB."""
+    K = cameraParams.K if hasattr(cameraParams, "K") else np.asarray(cameraParams.IntrinsicMatrix).T
+    # MATLAB pixel coordinates and K share the 1-based convention: no shift is applied
+    r = ops.p3p_ransac(imagePoints, worldPoints, K, num_hyp=MaxNumTrials, max_reproj_err=MaxReprojectionError,
+                       confidence=Confidence / 100.0, seed=Seed, mode=1, min_inliers=4, sample_idx=SampleIdx)
+    return r["R"], r["t"].reshape(1, 3), r["inliers"], r["status"]
+
+
+def harris(img, patch_size, kappa):
+    """old/harris.m:1-25."""
+    return ops.corner_response(img, "harris", patch_size, kappa)
+
+
+def selectKeypoints(scores, num, r):
+    """old/selectKeypoints.m:1-16 -> 2 x num [row; col], 1-based."""
+    return ops.select_keypoints_greedy(scores, num, r)
+
+
+def p3p(worldPoints, imageVectors):
+    """old/p3p.m:41-217: 3 x 3 columns of world points / unit bearings -> 3 x 16 = four [C R] blocks."""
+    P = np.asarray(worldPoints, np.float64).T  # rows = points
+    f = np.asarray(imageVectors, np.float64).T
+    o = ops.p3p_batch(P[None], f[None])[0]
+    out = np.zeros((3, 16))
+    for s in range(4):
+        out[:, 4 * s] = o[s, :3]
+        out[:, 4 * s + 1:4 * s + 4] = o[s, 3:].reshape(3, 3)
+    return out
+
+
+def _new_state():
+    return SimpleNamespace(landmarks=np.zeros((0, 3)), keypoints=np.zeros((0, 2)), reproError=np.zeros((0,)),
+                           candidate_keypoints=np.zeros((0, 2)), candidate_first_keypoints=np.zeros((0, 2)),
+                           candidate_first_poses=[], candidate_time_indxs=np.zeros((0,), np.int64))
+
+
+def _triangulate_tracked(prev_state, candidate_tracked, val_cand, curr_pose, K):
+    """One batched call for every validly tracked candidate (the loop body :93-113 up to the gates)."""
+    idx = np.flatnonzero(val_cand)
+    if idx.size == 0:
+        return idx, np.zeros((0, 3)), np.zeros(0), np.zeros(0), np.zeros(0, bool)
+    poses = np.stack([np.asarray(prev_state.candidate_first_poses[i], np.float64) for i in idx])
+    X, rep, ang, ok = ops.triangulate_candidates(np.asarray(prev_state.candidate_first_keypoints)[idx],
+                                                 np.asarray(candidate_tracked)[idx], poses, curr_pose, K)
+    return idx, X, rep, ang, ok
+
+
+def candidateTriangulation(prev_img, prev_state, curr_img, curr_pose, camera_params, tracker,
+                           max_temporal_recall=50, admissible_angular_threshold=2.5, max_landmarks=500,
+                           max_reprojection_err=2, maxDepth=1000):
+    """modules/candidateTriangulation.m:1-117 (free function, first-generation policy: FIFO eviction
+    at the cap :88-91, extra Z > 0 gate :56).  Geometry runs batched on the GPU; the order-dependent
+    merge is applied in candidate order on the host."""
+    del maxDepth
+    K = camera_params.K
+    kt, val_key, _ = tracker.track(prev_img, curr_img, prev_state.keypoints)
+    landmarks = np.asarray(prev_state.landmarks)[val_key]
+    keypoints = kt[val_key]
+    ct, val_cand, _ = tracker.track(prev_img, curr_img, prev_state.candidate_keypoints)
+    tracked_keypoints = ct[val_cand]
+    cs = _new_state()
+    idx, X, rep, ang, ok = _triangulate_tracked(prev_state, ct, val_cand, curr_pose, K)
+    lm, kp = list(landmarks), list(keypoints)
+    ck, cfk, cfp, cti = [], [], [], []
+    for j, i in enumerate(idx):
+        if not (ok[j] and X[j, 2] > 0 and rep[j] <= max_reprojection_err):
+            continue
+        if ang[j] > admissible_angular_threshold:
+            if len(lm) >= max_landmarks:
+                lm = lm[1:]; kp = kp[1:]
+            lm.append(X[j]); kp.append(ct[i])
+        elif prev_state.candidate_time_indxs[i] > -max_temporal_recall:
+            ck.append(ct[i]); cfk.append(prev_state.candidate_first_keypoints[i])
+            cfp.append(prev_state.candidate_first_poses[i]); cti.append(prev_state.candidate_time_indxs[i] - 1)
+    cs.landmarks = np.array(lm).reshape(-1, 3); cs.keypoints = np.array(kp).reshape(-1, 2)
+    cs.candidate_keypoints = np.array(ck).reshape(-1, 2); cs.candidate_first_keypoints = np.array(cfk).reshape(-1, 2)
+    cs.candidate_first_poses = cfp; cs.candidate_time_indxs = np.array(cti, np.int64)
+    del cs.reproError
+    return cs, tracked_keypoints
+
+
+class VisualOdometry:
+    """modules/VisualOdometry.m: constructor defaults :22-25, tracker :33-37."""
+
+    def __init__(self, cameraParams, imageSize, angularThreshold=1.0, maxTemporalRecall=10, maxNumLandmarks=300,
+                 maxReprojectionError=3, Seed=1023):
+        self.cameraParams = cameraParams
+        self.imageSize = imageSize
+        self.angularThreshold = float(angularThreshold)
+        self.maxTemporalRecall = int(maxTemporalRecall)
+        self.maxNumLandmarks = int(maxNumLandmarks)
+        self.maxReprojectionError = float(maxReprojectionError)
+        self.tracker = KLTTracker(NumPyramidLevels=4, MaxBidirectionalError=2, BlockSize=(41, 41), MaxIterations=50)
+        self.seed = int(Seed)
+        self.frame = 0
+
+    def computeReprojectionError(self, landmarks, keypoints, cameraPose):
+        """modules/VisualOdometry.m:48-61."""
+        return ops.reproj_error(keypoints, landmarks, cameraPose, self.cameraParams.K)
+
+    def candidateTriangulation(self, prev_img, prev_state, curr_img, curr_state, curr_pose):
+        """modules/VisualOdometry.m:63-151: replace-worst policy at the cap (:116-122), ageing (:130-139)."""
+        landmarks = list(np.asarray(curr_state.landmarks).reshape(-1, 3))
+        keypoints = list(np.asarray(curr_state.keypoints).reshape(-1, 2))
+        repro = list(np.asarray(curr_state.reproError).reshape(-1))
+        ct, val_cand, _ = self.tracker.track(prev_img, curr_img, prev_state.candidate_keypoints)
+        tracked_keypoints = ct[val_cand]
+        idx, X, rep, ang, ok = _triangulate_tracked(prev_state, ct, val_cand, curr_pose, self.cameraParams.K)
+        ck, cfk, cfp, cti = [], [], [], []
+        for j, i in enumerate(idx):
+            # :89-90 maximum BEFORE this iteration's edits (first maximum wins)
+            if repro:
+                mi = int(np.argmax(repro)); mx = repro[mi]
+            else:
+                mi, mx = -1, -np.inf
+            if not (ok[j] and rep[j] <= self.maxReprojectionError):  # :106-111
+                continue
+            if ang[j] > self.angularThreshold:                        # :113
+                if len(landmarks) >= self.maxNumLandmarks and rep[j] <= mx:  # :116-122
+                    del landmarks[mi]; del keypoints[mi]; del repro[mi]
+                if len(landmarks) < self.maxNumLandmarks:             # :123-127
+                    landmarks.append(X[j]); keypoints.append(ct[i]); repro.append(rep[j])
+            elif prev_state.candidate_time_indxs[i] > -self.maxTemporalRecall:  # :130-139
+                ck.append(ct[i]); cfk.append(prev_state.candidate_first_keypoints[i])
+                cfp.append(prev_state.candidate_first_poses[i]); cti.append(prev_state.candidate_time_indxs[i] - 1)
+        curr_state.landmarks = np.array(landmarks).reshape(-1, 3)
+        curr_state.keypoints = np.array(keypoints).reshape(-1, 2)
+        curr_state.reproError = np.array(repro).reshape(-1)
+        curr_state.candidate_keypoints = np.array(ck).reshape(-1, 2)
+        curr_state.candidate_first_keypoints = np.array(cfk).reshape(-1, 2)
+        curr_state.candidate_first_poses = cfp
+        curr_state.candidate_time_indxs = np.array(cti, np.int64)
+        return curr_state, tracked_keypoints
+
+    def processFrame(self, prev_img, curr_img, prev_state):
+        """[curr_state, curr_pose, pose_status] = processFrame(obj, prev_img, curr_img, prev_state)
+        (modules/VisualOdometry.m:264-346)."""
+        tk, val_idx, _ = self.tracker.track(prev_img, curr_img, prev_state.keypoints)           # :278-281
+        vk = tk[val_idx]
+        vl = np.asarray(prev_state.landmarks)[val_idx]
+        self.frame += 1
+        R, T, _inl, status = estimateWorldCameraPose(vk.astype(np.float64), vl.astype(np.float64),  # :285-289
+                                                     self.cameraParams, MaxNumTrials=5000, Confidence=99,
+                                                     MaxReprojectionError=2, Seed=self.seed + self.frame)
+        curr_pose = np.vstack([R, T])                                                            # :318
+        err = self.computeReprojectionError(vl, vk, curr_pose) if len(vk) else np.zeros(0)       # :298-300
+        keep = err < self.maxReprojectionError                                                   # :302
+        cs = _new_state()
+        cs.keypoints = vk[keep]; cs.landmarks = vl[keep]; cs.reproError = err[keep]              # :308-315
+        cs, _ = self.candidateTriangulation(prev_img, prev_state, curr_img, cs, curr_pose)       # :322
+        both = np.vstack([cs.keypoints.reshape(-1, 2), cs.candidate_keypoints.reshape(-1, 2)])
+        new = selectCandidateKeypoints(curr_img, both, MinQuality=0.001, FilterSize=5, MinDistance=7,
+                                       CandidatesToKeep=100)                                     # :330-335
+        cs.candidate_keypoints = np.vstack([cs.candidate_keypoints.reshape(-1, 2), new])         # :338-345
+        cs.candidate_first_keypoints = np.vstack([cs.candidate_first_keypoints.reshape(-1, 2), new])
+        cs.candidate_first_poses = list(cs.candidate_first_poses) + [curr_pose] * len(new)
+        cs.candidate_time_indxs = np.concatenate([cs.candidate_time_indxs, -np.ones(len(new), np.int64)])
+        return cs, curr_pose, status
