@@ -218,31 +218,62 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int32_t* __restrict_
 }
 
 // ---- N8 distance filter: keep[i] = no existing point with d2 < thr_d2 (thr_d2 = smallest float
-// whose correctly rounded sqrtf reaches min_distance, computed on the host)
-__global__ __launch_bounds__(256) void k_distance(const float* __restrict__ cu, const float* __restrict__ cv,
-                                                   const int32_t* __restrict__ m0, const float* __restrict__ eu,
-                                                   const float* __restrict__ ev, int ne, float thr_d2, uint8_t* keep) {
-    __shared__ float su[1024], sv[1024];
-    const int m = *m0;
-    if ((int)(blockIdx.x * 256) >= m) return;
+// whose correctly rounded sqrtf reaches min_distance, computed on the host).  The existing points
+// are bucketed into a uniform grid of cell size cs >= min_distance + 1 (counting sort: count, scan,
+// fill); a corner then tests the 3 x 3 cells around its own.  A pair closer than min_distance
+// differs by less than 1 - 1/cs cells per axis, so the +-1 neighbourhood is exhaustive even with
+// the rounding of the float cell computation; clamping out-of-image points into the border cells
+// only moves them towards the cells that must see them.  The verdict is an "any", hence independent
+// of the (atomic) order inside a cell: bit-exact against the oracle's all-pairs loop.
+struct GridArgs {
+    const float *eu, *ev; int ne; float inv_cs; int gu, gv;
+    int32_t *count, *offs, *cursor; float *su, *sv;
+};
+__device__ __forceinline__ int grid_cell1(float x, float inv_cs, int g) {
+    const float c = floorf(x * inv_cs);
+    return !(c >= 0.0f) ? 0 : (c > (float)(g - 1) ? g - 1 : (int)c); // NaN -> cell 0
+}
+__global__ __launch_bounds__(256) void k_grid_count(GridArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool act = i < m;
-    const float pu = act ? cu[i] : 0.0f, pv = act ? cv[i] : 0.0f;
+    if (i >= a.ne) return;
+    const int c = grid_cell1(a.ev[i], a.inv_cs, a.gv) * a.gu + grid_cell1(a.eu[i], a.inv_cs, a.gu);
+    atomicAdd(&a.count[c], 1);
+}
+__global__ __launch_bounds__(256) void k_grid_fill(GridArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.ne) return;
+    const float u = a.eu[i], v = a.ev[i];
+    const int c = grid_cell1(v, a.inv_cs, a.gv) * a.gu + grid_cell1(u, a.inv_cs, a.gu);
+    const int pos = a.offs[c] + atomicAdd(&a.cursor[c], 1);
+    a.su[pos] = u; a.sv[pos] = v;
+}
+__global__ __launch_bounds__(256) void k_distance(const float* __restrict__ cu, const float* __restrict__ cv,
+                                                   const int32_t* __restrict__ m0, GridArgs g, float thr_d2,
+                                                   uint8_t* keep) {
+    const int m = *m0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const float pu = cu[i], pv = cv[i];
+    const int c0u = grid_cell1(pu, g.inv_cs, g.gu), c0v = grid_cell1(pv, g.inv_cs, g.gv);
     bool k = true;
-    for (int base = 0; base < ne; base += 1024) {
-        const int cnt = min(1024, ne - base);
-        __syncthreads();
-        for (int j = threadIdx.x; j < cnt; j += 256) { su[j] = eu[base + j]; sv[j] = ev[base + j]; }
-        __syncthreads();
-        if (k && act) {
-            for (int j = 0; j < cnt; ++j) {
-                const float dx = pu - su[j], dy = pv - sv[j];
-                const float d2 = dx * dx + dy * dy;
-                if (d2 < thr_d2) { k = false; break; }
-            }
+    for (int dv = -1; dv <= 1 && k; ++dv) {
+        const int cv_ = c0v + dv;
+        if (cv_ < 0 || cv_ >= g.gv) continue;
+        const int ua = max(c0u - 1, 0), ub = min(c0u + 1, g.gu - 1);
+        // the three cells of one grid row are contiguous in the sorted arrays
+        const int j0 = g.offs[cv_ * g.gu + ua];
+        const int j1 = g.offs[cv_ * g.gu + ub] + g.count[cv_ * g.gu + ub];
+        for (int j = j0; j < j1; ++j) {
+            const float dx = pu - g.su[j], dy = pv - g.sv[j];
+            const float d2 = dx * dx + dy * dy;
+            if (d2 < thr_d2) { k = false; break; }
         }
     }
-    if (act) keep[i] = k ? 1 : 0;
+    keep[i] = k ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_keep_all(const int32_t* __restrict__ m0, uint8_t* keep) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < *m0) keep[i] = 1;
 }
 
 // ---- N8 selectUniform + ordered output.  Single block; cell tables in global scratch.
@@ -451,6 +482,14 @@ static float d2_threshold(float d) {
     return x;
 }
 
+void vo_select_grid_dims(int nu, int nv, double min_distance, float* cs, int* gu, int* gv) {
+    float c = (float)min_distance + 1.0f;
+    if (!(c >= 2.0f)) c = 2.0f;
+    // keep the table small for tiny distances on big images
+    while ((double)(nu / c + 2) * (double)(nv / c + 2) > 4.0e6) c *= 2.0f;
+    *cs = c; *gu = (int)(nu / c) + 2; *gv = (int)(nv / c) + 2;
+}
+
 int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is_rows, const float* d_eu,
                      const float* d_ev, int n_exist, const vo_sel_opts* o, vo_sel_work* w, float* d_out_u,
                      float* d_out_v, int32_t* d_out_lin, double* d_out_metric, int32_t* d_out_count) {
@@ -466,8 +505,21 @@ int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is
     hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, ctx->stream, w->resp, nu, nv, w->maxbits,
                        o->min_quality, 1, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric);
     const int dblk = (w->cap + 255) / 256;
-    hipLaunchKernelGGL(k_distance, dim3(dblk), dim3(256), 0, ctx->stream, w->lu, w->lv, w->m0, d_eu, d_ev, n_exist,
-                       d2_threshold((float)o->min_distance), w->keep);
+    const float thr_d2 = d2_threshold((float)o->min_distance);
+    if (n_exist == 0 || !(thr_d2 > 0.0f)) {
+        hipLaunchKernelGGL(k_keep_all, dim3(dblk), dim3(256), 0, ctx->stream, w->m0, w->keep);
+    } else {
+        GridArgs g;
+        g.eu = d_eu; g.ev = d_ev; g.ne = n_exist; g.inv_cs = 1.0f / w->grid_cs; g.gu = w->grid_gu; g.gv = w->grid_gv;
+        g.count = w->grid_count; g.offs = w->grid_offs; g.cursor = w->grid_cursor; g.su = w->grid_su; g.sv = w->grid_sv;
+        const int ncell = g.gu * g.gv;
+        VO_HIP_CHECK(ctx, hipMemsetAsync(g.count, 0, sizeof(int32_t) * 2 * (size_t)ncell, ctx->stream)); // count + cursor
+        const int eblk = (n_exist + 255) / 256;
+        hipLaunchKernelGGL(k_grid_count, dim3(eblk), dim3(256), 0, ctx->stream, g);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, g.count, ncell, g.offs, w->grid_total, 0x7fffffff);
+        hipLaunchKernelGGL(k_grid_fill, dim3(eblk), dim3(256), 0, ctx->stream, g);
+        hipLaunchKernelGGL(k_distance, dim3(dblk), dim3(256), 0, ctx->stream, w->lu, w->lv, w->m0, g, thr_d2, w->keep);
+    }
     UniArgs a;
     a.cu = w->lu; a.cv = w->lv; a.metric = w->metric; a.lin = w->lin; a.keep = w->keep; a.sel = w->sel; a.m0 = w->m0;
     a.n_keep = o->keep; a.nu = nu; a.nv = nv; a.u_is_rows = u_is_rows;
