@@ -24,8 +24,7 @@ constexpr int LK_M = 3; // LDS patch margin in pixels
 
 struct LKArgs {
     const float *A, *B;
-    int nus[VO_MAX_LEVELS], nvs[VO_MAX_LEVELS];
-    long offs[VO_MAX_LEVELS];
+    int nu0, nv0;
     int levels, wu, wv, npx, max_iters, n;
     float eps2;
     double max_bidir;
@@ -36,8 +35,9 @@ struct LKArgs {
     unsigned long long* counters; // VO_COUNTER_SHARDS x 4
 };
 
-template <int BW_, int BH_, int LU_, int LV_, int PW_, bool COL_>
+template <int BW_, int BH_, int LU_, int LV_, int PW_, bool COL_, int WAVES_>
 struct Cfg {
+    static constexpr int WAVES = WAVES_; // occupancy target (waves per SIMD) handed to the register allocator
     static constexpr int BW = BW_, BH = BH_, LU = LU_, LV = LV_, PW = PW_;
     static constexpr bool COL = COL_;
     static constexpr int PH = LV * BH + 1 + 2 * LK_M;
@@ -46,10 +46,10 @@ struct Cfg {
     static_assert(LU * LV <= 64, "more blocks than lanes");
 };
 // pitches from a bank-conflict search over (lane -> block) orders, see DESIGN.md
-using CfgS = Cfg<3, 3, 7, 7, 39, false>;  // windows up to 21 x 21
-using CfgM = Cfg<5, 4, 7, 8, 43, true>;   // up to 35 x 32
-using CfgL = Cfg<6, 5, 7, 9, 49, false>;  // up to 42 x 45 (the reference's 41 x 41)
-using CfgX = Cfg<7, 7, 8, 8, 68, true>;   // up to 56 x 56 (51 x 51 of module_tests/updateW2D3D_test.m:20)
+using CfgS = Cfg<3, 3, 7, 7, 39, false, 5>;  // windows up to 21 x 21
+using CfgM = Cfg<5, 4, 7, 8, 43, true, 4>;   // up to 35 x 32
+using CfgL = Cfg<6, 5, 7, 9, 49, false, 3>;  // up to 42 x 45 (the reference's 41 x 41)
+using CfgX = Cfg<7, 7, 8, 8, 68, true, 1>;   // up to 56 x 56 (51 x 51 of module_tests/updateW2D3D_test.m:20)
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
@@ -68,18 +68,50 @@ __device__ __forceinline__ float wave_sum(float x) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 
-// stage the whole PW x PH patch (replicate-clamped coordinates) -- every LDS word a lane can read
-// holds image data, so masked pixels never see NaN garbage
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// pyramid geometry of level l (wave-uniform scalar arithmetic; same rule as frame_prepare)
+__device__ __forceinline__ void level_dims(int nu0, int nv0, int l, int& nu, int& nv, long& off) {
+    nu = nu0; nv = nv0; off = 0;
+    for (int k = 0; k < l; ++k) { off += (long)nu * nv; nu = (nu + 1) >> 1; nv = (nv + 1) >> 1; }
+}
+
+// Stage the whole PW x PH patch (replicate-clamped coordinates): every LDS word a lane can read
+// holds image data, so masked pixels never see NaN garbage.  Lane = patch column; the row walks a
+// wave-uniform loop, so the row base is scalar and each element costs one saddr global load and one
+// ds_write with an immediate offset -- no per-element address arithmetic on the VALU.
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(1))) const float glb_float;
+
 template <class C>
 __device__ __forceinline__ void stage(float* patch, const float* __restrict__ img, int nu, int nv, int ou, int ov,
                                       int lane) {
     __syncthreads();
-    constexpr int TOT = C::PW * C::PH;
-#pragma unroll 8
-    for (int idx = lane; idx < TOT; idx += 64) {
-        const int r = idx / C::PW, c = idx - r * C::PW;
-        patch[idx] = img[(long)clampi(ov + r, 0, nv - 1) * nu + clampi(ou + c, 0, nu - 1)];
+    // LDS-DMA: each wave-instruction moves one patch row (lane = column) straight into LDS; no VGPR
+    // staging, every row in flight at once.  LDS address = M0 base (the row) + lane * 4.
+    lds_float* lp = reinterpret_cast<lds_float*>(reinterpret_cast<uintptr_t>(patch));
+#pragma unroll
+    for (int c0 = 0; c0 < C::PW; c0 += 64) {
+        const int c = c0 + lane;
+        if (c < C::PW) {
+            const int cc = clampi(ou + c, 0, nu - 1);
+            if (ov >= 0 && ov + C::PH <= nv) { // interior rows (wave-uniform): the row base just advances
+                const float* rowp = img + (long)ov * nu;
+#pragma unroll
+                for (int r = 0; r < C::PH; ++r) {
+                    __builtin_amdgcn_global_load_lds((glb_float*)(rowp + cc), lp + r * C::PW + c0, 4, 0, 0);
+                    rowp += nu;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < C::PH; ++r) {
+                    const float* rowp = img + (long)clampi(ov + r, 0, nv - 1) * nu;
+                    __builtin_amdgcn_global_load_lds((glb_float*)(rowp + cc), lp + r * C::PW + c0, 4, 0, 0);
+                }
+            }
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
 
@@ -91,19 +123,19 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     constexpr int BW = C::BW, BH = C::BH, PW = C::PW;
     float T[BH][BW], Tu[BH][BW], Tv[BH][BW];
     const int ru = (a.wu - 1) / 2, rv = (a.wv - 1) / 2;
-    const int nu0 = a.nus[0], nv0 = a.nvs[0];
+    const int nu0 = a.nu0, nv0 = a.nv0;
     double gu = 0, gv = 0;
     int flags = 0;
     for (int l = a.levels - 1; l >= 0; --l) {
         const double s = (double)(1 << l);
-        const int nu = a.nus[l], nv = a.nvs[l];
-        const long lo = a.offs[l];
+        int nu, nv; long lo;
+        level_dims(nu0, nv0, l, nu, nv, lo);
         const double plu = su / s, plv = sv / s;
         float sxx = 0, sxy = 0, syy = 0;
         {   // ---- template set-up: E = samples on the window grown by one pixel, Sobel/8 of E ----
             const double flu = floor(plu), flv = floor(plv);
             const float fu = (float)(plu - flu), fv = (float)(plv - flv);
-            stage<C>(patch, A + lo, nu, nv, (int)flu - ru - 1, (int)flv - rv - 1, lane);
+            stage<C>(patch, A + lo, nu, nv, uni((int)flu) - ru - 1, uni((int)flv) - rv - 1, lane);
             float E[BH + 2][BW + 2];
             float hp[BW + 2];
 #pragma unroll
@@ -154,7 +186,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                     break;
                 }
                 const double flu = floor(cu), flv = floor(cv);
-                const int iu = (int)flu, iv = (int)flv;
+                const int iu = uni((int)flu), iv = uni((int)flv);
                 int fi = iu - ru - pou, fj = iv - rv - pov;
                 if (!staged || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) {
                     pou = iu - ru - LK_M; pov = iv - rv - LK_M;
@@ -203,7 +235,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     ssd_out = 0.0f;
     if (!(flags & 1)) { // N5 residual at level 0; T holds the level-0 template
         const double flu = floor(qu), flv = floor(qv);
-        stage<C>(patch, B, nu0, nv0, (int)flu - ru - LK_M, (int)flv - rv - LK_M, lane);
+        stage<C>(patch, B, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane);
         const float fu = (float)(qu - flu), fv = (float)(qv - flv);
         const int base = lbase + LK_M * PW + LK_M;
         float ssd = 0;
@@ -232,7 +264,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
 }
 
 template <class C>
-__global__ __launch_bounds__(64) void k_lk(LKArgs a) {
+__global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
     __shared__ float patch[C::PW * C::PH];
     const int lane = threadIdx.x, kp = blockIdx.x;
     // lane -> block; lanes beyond LU*LV read block 0's pixels with an all-masked window
@@ -291,7 +323,7 @@ int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d
     if (A->nu != B->nu || A->nv != B->nv || A->levels != B->levels) { ctx->last_error = "klt: frame shapes differ"; return VO_ERR_BAD_ARG; }
     LKArgs a;
     a.A = A->I; a.B = B->I;
-    for (int l = 0; l < A->levels; ++l) { a.nus[l] = A->nus[l]; a.nvs[l] = A->nvs[l]; a.offs[l] = A->offs[l]; }
+    a.nu0 = A->nu; a.nv0 = A->nv;
     a.levels = A->levels; a.wu = wu; a.wv = wv;
     a.npx = wu * wv; a.max_iters = max_iters; a.n = n;
     a.eps2 = (float)(eps * eps); a.max_bidir = max_bidir;
