@@ -48,7 +48,7 @@ struct Cfg {
 // pitches from a bank-conflict search over (lane -> block) orders, see DESIGN.md
 using CfgS = Cfg<3, 3, 7, 7, 39, false, 5>;  // windows up to 21 x 21
 using CfgM = Cfg<5, 4, 7, 8, 43, true, 4>;   // up to 35 x 32
-using CfgL = Cfg<6, 5, 7, 9, 49, false, 3>;  // up to 42 x 45 (the reference's 41 x 41)
+using CfgL = Cfg<6, 5, 7, 9, 49, false, 4>;  // up to 42 x 45 (the reference's 41 x 41)
 using CfgX = Cfg<7, 7, 8, 8, 68, true, 1>;   // up to 56 x 56 (51 x 51 of module_tests/updateW2D3D_test.m:20)
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -115,10 +115,14 @@ __device__ __forceinline__ void stage(float* patch, const float* __restrict__ im
     __syncthreads();
 }
 
-// one direction A -> B (N4).  returns flags: bit0 lost, bit1 flat at level 0
+__device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+
+// one direction A -> B (N4).  returns flags: bit0 lost, bit1 flat at level 0.
+// Wave-uniform scalars (sub-pixel fractions, the 2x2 inverse, the running displacement) are pushed
+// back to SGPRs after every VALU step so that the register file holds little besides the template.
 template <class C>
 __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float* __restrict__ B, double su, double sv,
-                      float* patch, int lane, int lbase, int bi0, int bj0, double& qu, double& qv, float& ssd_out,
+                      float* patch, int lane, int lbase, unsigned long long mask, double& qu, double& qv, float& ssd_out,
                       unsigned& iters, unsigned& setups) {
     constexpr int BW = C::BW, BH = C::BH, PW = C::PW;
     float T[BH][BW], Tu[BH][BW], Tv[BH][BW];
@@ -126,44 +130,49 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     const int nu0 = a.nu0, nv0 = a.nv0;
     double gu = 0, gv = 0;
     int flags = 0;
+    bool b0_staged = false; // the patch holds level 0 of image B at origin (b0_ou, b0_ov)
+    int b0_ou = 0, b0_ov = 0;
     for (int l = a.levels - 1; l >= 0; --l) {
         const double s = (double)(1 << l);
         int nu, nv; long lo;
         level_dims(nu0, nv0, l, nu, nv, lo);
         const double plu = su / s, plv = sv / s;
         float sxx = 0, sxy = 0, syy = 0;
-        {   // ---- template set-up: E = samples on the window grown by one pixel, Sobel/8 of E ----
+        {   // ---- template set-up: E = samples on the window grown by one pixel, Sobel/8 of E.
+            // Rows stream through a 3-row ring so that only 3 x (BW+2) samples are live at a time.
             const double flu = floor(plu), flv = floor(plv);
-            const float fu = (float)(plu - flu), fv = (float)(plv - flv);
+            const float fu = unif((float)(plu - flu)), fv = unif((float)(plv - flv));
             stage<C>(patch, A + lo, nu, nv, uni((int)flu) - ru - 1, uni((int)flv) - rv - 1, lane);
-            float E[BH + 2][BW + 2];
+            float E[3][BW + 2];
             float hp[BW + 2];
 #pragma unroll
             for (int r = 0; r < BH + 3; ++r) {
-                float p[BW + 3], h[BW + 2];
+                float p[BW + 3];
 #pragma unroll
                 for (int c = 0; c < BW + 3; ++c) p[c] = patch[lbase + r * PW + c];
 #pragma unroll
-                for (int c = 0; c < BW + 2; ++c) h[c] = p[c] + fu * (p[c + 1] - p[c]);
+                for (int c = 0; c < BW + 2; ++c) p[c] = p[c] + fu * (p[c + 1] - p[c]); // p[c] := H(r, c)
                 if (r > 0) {
 #pragma unroll
-                    for (int c = 0; c < BW + 2; ++c) E[r - 1][c] = hp[c] + fv * (h[c] - hp[c]);
+                    for (int c = 0; c < BW + 2; ++c) E[(r - 1) % 3][c] = hp[c] + fv * (p[c] - hp[c]);
                 }
 #pragma unroll
-                for (int c = 0; c < BW + 2; ++c) hp[c] = h[c];
+                for (int c = 0; c < BW + 2; ++c) hp[c] = p[c];
+                if (r >= 3) { // E rows j, j+1, j+2 are complete: emit template row j
+                    const int j = r - 3;
+                    const float* e0 = E[j % 3]; const float* e1 = E[(j + 1) % 3]; const float* e2 = E[(j + 2) % 3];
+#pragma unroll
+                    for (int i = 0; i < BW; ++i) {
+                        const bool in = (mask >> (j * BW + i)) & 1ull;
+                        const float tu = ((e0[i + 2] - e0[i]) + 2.0f * (e1[i + 2] - e1[i]) + (e2[i + 2] - e2[i])) * 0.125f;
+                        const float tv = ((e2[i] - e0[i]) + 2.0f * (e2[i + 1] - e0[i + 1]) + (e2[i + 2] - e0[i + 2])) * 0.125f;
+                        T[j][i] = e1[i + 1];
+                        Tu[j][i] = in ? tu : 0.0f;
+                        Tv[j][i] = in ? tv : 0.0f;
+                        sxx += Tu[j][i] * Tu[j][i]; sxy += Tu[j][i] * Tv[j][i]; syy += Tv[j][i] * Tv[j][i];
+                    }
+                }
             }
-#pragma unroll
-            for (int j = 0; j < BH; ++j)
-#pragma unroll
-                for (int i = 0; i < BW; ++i) {
-                    const bool in = (bi0 + i < a.wu) && (bj0 + j < a.wv);
-                    const float tu = ((E[j][i + 2] - E[j][i]) + 2.0f * (E[j + 1][i + 2] - E[j + 1][i]) + (E[j + 2][i + 2] - E[j + 2][i])) * 0.125f;
-                    const float tv = ((E[j + 2][i] - E[j][i]) + 2.0f * (E[j + 2][i + 1] - E[j][i + 1]) + (E[j + 2][i + 2] - E[j][i + 2])) * 0.125f;
-                    T[j][i] = E[j + 1][i + 1];
-                    Tu[j][i] = in ? tu : 0.0f;
-                    Tv[j][i] = in ? tv : 0.0f;
-                    sxx += Tu[j][i] * Tu[j][i]; sxy += Tu[j][i] * Tv[j][i]; syy += Tv[j][i] * Tv[j][i];
-                }
             ++setups;
         }
         const double Guu = (double)wave_sum(sxx), Guv = (double)wave_sum(sxy), Gvv = (double)wave_sum(syy);
@@ -175,52 +184,59 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
         if (flat) {
             if (l == 0) flags |= 2;
         } else {
-            const float iuu = (float)(Gvv / det), iuv = (float)(-Guv / det), ivv = (float)(Guu / det);
+            const float iuu = unif((float)(Gvv / det)), iuv = unif((float)(-Guv / det)), ivv = unif((float)(Guu / det));
+            // position = (ibu + fbu + du, ibv + fbv + dv): integer base + float remainder
             const double bu0 = plu + gu, bv0 = plv + gv;
+            const double fbu0 = floor(bu0), fbv0 = floor(bv0);
+            const int ibu = uni((int)fbu0), ibv = uni((int)fbv0);
+            const float fbu = unif((float)(bu0 - fbu0)), fbv = unif((float)(bv0 - fbv0));
+            const float sf = (float)(1 << l), umax = (float)(nu0 - 1), vmax = (float)(nv0 - 1);
             bool staged = false;
             int pou = 0, pov = 0;
             for (int it = 0; it < a.max_iters; ++it) {
-                const double cu = bu0 + (double)du, cv = bv0 + (double)dv;
-                if (!(cu * s >= 0.0 && cu * s <= (double)(nu0 - 1) && cv * s >= 0.0 && cv * s <= (double)(nv0 - 1))) {
+                const float tu = fbu + du, tv = fbv + dv;
+                const float cu0 = ((float)ibu + tu) * sf, cv0 = ((float)ibv + tv) * sf; // level-0 position (N4 lost test)
+                if (!(cu0 >= 0.0f && cu0 <= umax && cv0 >= 0.0f && cv0 <= vmax)) {
                     flags |= 1;
                     break;
                 }
-                const double flu = floor(cu), flv = floor(cv);
-                const int iu = uni((int)flu), iv = uni((int)flv);
+                const float flu = floorf(tu), flv = floorf(tv);
+                const int iu = ibu + uni((int)flu), iv = ibv + uni((int)flv);
                 int fi = iu - ru - pou, fj = iv - rv - pov;
                 if (!staged || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) {
                     pou = iu - ru - LK_M; pov = iv - rv - LK_M;
                     stage<C>(patch, B + lo, nu, nv, pou, pov, lane);
                     staged = true;
                     fi = LK_M; fj = LK_M;
+                    if (l == 0) { b0_staged = true; b0_ou = pou; b0_ov = pov; }
                 }
-                const float fu = (float)(cu - flu), fv = (float)(cv - flv);
+                const float fu = unif(tu - flu), fv = unif(tv - flv);
                 const int base = lbase + fj * PW + fi;
                 float bu = 0, bv = 0;
                 float hp[BW];
 #pragma unroll
                 for (int r = 0; r < BH + 1; ++r) {
-                    float p[BW + 1], h[BW];
+                    float p[BW + 1];
 #pragma unroll
                     for (int c = 0; c < BW + 1; ++c) p[c] = patch[base + r * PW + c];
 #pragma unroll
-                    for (int c = 0; c < BW; ++c) h[c] = p[c] + fu * (p[c + 1] - p[c]);
+                    for (int c = 0; c < BW; ++c) p[c] = p[c] + fu * (p[c + 1] - p[c]);
                     if (r > 0) {
 #pragma unroll
                         for (int c = 0; c < BW; ++c) {
-                            const float e = T[r - 1][c] - (hp[c] + fv * (h[c] - hp[c]));
+                            const float e = T[r - 1][c] - (hp[c] + fv * (p[c] - hp[c]));
                             bu += e * Tu[r - 1][c];
                             bv += e * Tv[r - 1][c];
                         }
                     }
 #pragma unroll
-                    for (int c = 0; c < BW; ++c) hp[c] = h[c];
+                    for (int c = 0; c < BW; ++c) hp[c] = p[c];
                 }
                 const float Bu = wave_sum(bu), Bv = wave_sum(bv);
                 ++iters;
-                const float ddu = iuu * Bu + iuv * Bv;
-                const float ddv = iuv * Bu + ivv * Bv;
-                du += ddu; dv += ddv;
+                const float ddu = unif(iuu * Bu + iuv * Bv);
+                const float ddv = unif(iuv * Bu + ivv * Bv);
+                du = unif(du + ddu); dv = unif(dv + ddv);
                 if (ddu * ddu + ddv * ddv < a.eps2) break;
             }
         }
@@ -235,28 +251,33 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     ssd_out = 0.0f;
     if (!(flags & 1)) { // N5 residual at level 0; T holds the level-0 template
         const double flu = floor(qu), flv = floor(qv);
-        stage<C>(patch, B, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane);
-        const float fu = (float)(qu - flu), fv = (float)(qv - flv);
-        const int base = lbase + LK_M * PW + LK_M;
+        const int iu = uni((int)flu), iv = uni((int)flv);
+        int fi = iu - ru - b0_ou, fj = iv - rv - b0_ov;
+        if (!b0_staged || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) { // else reuse the last level-0 patch
+            stage<C>(patch, B, nu0, nv0, iu - ru - LK_M, iv - rv - LK_M, lane);
+            fi = LK_M; fj = LK_M;
+        }
+        const float fu = unif((float)(qu - flu)), fv = unif((float)(qv - flv));
+        const int base = lbase + fj * PW + fi;
         float ssd = 0;
         float hp[BW];
 #pragma unroll
         for (int r = 0; r < BH + 1; ++r) {
-            float p[BW + 1], h[BW];
+            float p[BW + 1];
 #pragma unroll
             for (int c = 0; c < BW + 1; ++c) p[c] = patch[base + r * PW + c];
 #pragma unroll
-            for (int c = 0; c < BW; ++c) h[c] = p[c] + fu * (p[c + 1] - p[c]);
+            for (int c = 0; c < BW; ++c) p[c] = p[c] + fu * (p[c + 1] - p[c]);
             if (r > 0) {
 #pragma unroll
                 for (int c = 0; c < BW; ++c) {
-                    const bool in = (bi0 + c < a.wu) && (bj0 + r - 1 < a.wv);
-                    const float e = T[r - 1][c] - (hp[c] + fv * (h[c] - hp[c]));
+                    const bool in = (mask >> ((r - 1) * BW + c)) & 1ull;
+                    const float e = T[r - 1][c] - (hp[c] + fv * (p[c] - hp[c]));
                     ssd += in ? e * e : 0.0f;
                 }
             }
 #pragma unroll
-            for (int c = 0; c < BW; ++c) hp[c] = h[c];
+            for (int c = 0; c < BW; ++c) hp[c] = p[c];
         }
         ssd_out = wave_sum(ssd);
     }
@@ -271,18 +292,26 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
     int lu, lv;
     const bool live = lane < C::LU * C::LV;
     if (C::COL) { lu = lane / C::LV; lv = lane - lu * C::LV; } else { lv = lane / C::LU; lu = lane - lv * C::LU; }
-    const int bi0 = live ? lu * C::BW : C::MAXU; // mask origin: >= wu masks every pixel
-    const int bj0 = live ? lv * C::BH : C::MAXV;
     const int lbase = live ? (lv * C::BH) * C::PW + lu * C::BW : 0;
+    // bit (j * BW + i) = pixel (i, j) of this lane's block lies inside the wu x wv window
+    static_assert(C::BW * C::BH <= 64, "block mask does not fit");
+    unsigned long long mask64 = 0;
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < C::BH; ++j)
+#pragma unroll
+            for (int i = 0; i < C::BW; ++i)
+                if (lu * C::BW + i < a.wu && lv * C::BH + j < a.wv) mask64 |= 1ull << (j * C::BW + i);
+    }
     const double p0u = a.pu[kp], p0v = a.pv[kp];
     unsigned iters = 0, setups = 0;
     double fu, fv, bu = 0, bv = 0;
     float ssd, ssd2;
-    const int fl = lk_dir<C>(a, a.A, a.B, p0u, p0v, patch, lane, lbase, bi0, bj0, fu, fv, ssd, iters, setups);
+    const int fl = lk_dir<C>(a, a.A, a.B, p0u, p0v, patch, lane, lbase, mask64, fu, fv, ssd, iters, setups);
     bool ok = (fl == 0);
     float fb = __builtin_nanf("");
     if (!(fl & 1) && a.max_bidir >= 0.0) {
-        const int fl2 = lk_dir<C>(a, a.B, a.A, fu, fv, patch, lane, lbase, bi0, bj0, bu, bv, ssd2, iters, setups);
+        const int fl2 = lk_dir<C>(a, a.B, a.A, fu, fv, patch, lane, lbase, mask64, bu, bv, ssd2, iters, setups);
         if (fl2 & 1) ok = false;
         else {
             const double eu = p0u - bu, ev = p0v - bv;
