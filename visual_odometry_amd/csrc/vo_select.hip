@@ -284,9 +284,13 @@ struct UniArgs {
     float *out_u, *out_v; int32_t* out_lin; double* out_metric; int32_t* out_count;
 };
 
+constexpr int UNI_LDS_CELLS = 2048; // per-round cell tables live in LDS up to this many cells
+
 __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
     __shared__ int s_cnt[16];
     __shared__ int s_remaining, s_selected, s_round_sel;
+    __shared__ unsigned long long s_key[UNI_LDS_CELLS];
+    __shared__ int s_idx[UNI_LDS_CELLS];
     const int t = threadIdx.x, m = *a.m0;
     int loc = 0;
     for (int i = t; i < m; i += 1024) { a.sel[i] = 0; loc += a.keep[i] ? 1 : 0; }
@@ -306,17 +310,22 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
         long w = (h * W) / H; if (w < 1) w = 1; if (h * w > want) w = want / h;
         const int cells_u = (int)(a.u_is_rows ? h : w), cells_v = (int)(a.u_is_rows ? w : h);
         const int nc = cells_u * cells_v;
-        for (int k = t; k < nc; k += 1024) { a.cell_key[k] = 0ull; a.cell_idx[k] = 0x7fffffff; }
+        const bool lds = nc <= UNI_LDS_CELLS; // wave-uniform: LDS atomics when the table fits, else L2 atomics
+        for (int k = t; k < nc; k += 1024) {
+            if (lds) { s_key[k] = 0ull; s_idx[k] = 0x7fffffff; }
+            else { a.cell_key[k] = 0ull; a.cell_idx[k] = 0x7fffffff; }
+        }
         if (t == 0) s_round_sel = 0;
         __syncthreads();
-        // phase 1: per-cell maximum metric (metric > 0 for every corner, so key 0 = empty)
+        // phase 1: per-cell maximum metric (+1 so that a zero metric still differs from "empty")
         for (int i = t; i < m; i += 1024) {
             if (!a.keep[i] || a.sel[i]) continue;
             int bu = (int)floor(((double)a.cu[i] * (double)cells_u) / (double)a.nu);
             int bv = (int)floor(((double)a.cv[i] * (double)cells_v) / (double)a.nv);
             bu = clampi(bu, 0, cells_u - 1); bv = clampi(bv, 0, cells_v - 1);
-            // +1 so that a zero metric still differs from "empty"
-            atomicMax(&a.cell_key[bv * cells_u + bu], (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull);
+            const unsigned long long key = (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull;
+            if (lds) atomicMax(&s_key[bv * cells_u + bu], key);
+            else atomicMax(&a.cell_key[bv * cells_u + bu], key);
         }
         __threadfence_block();
         __syncthreads();
@@ -328,14 +337,15 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
             bu = clampi(bu, 0, cells_u - 1); bv = clampi(bv, 0, cells_v - 1);
             const int cell = bv * cells_u + bu;
             const unsigned long long key = (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull;
-            if (__hip_atomic_load(&a.cell_key[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key)
+            if (lds) { if (s_key[cell] == key) atomicMin(&s_idx[cell], i); }
+            else if (__hip_atomic_load(&a.cell_key[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key)
                 atomicMin(&a.cell_idx[cell], i);
         }
         __threadfence_block();
         __syncthreads();
         int got = 0;
         for (int k = t; k < nc; k += 1024) {
-            const int idx = __hip_atomic_load(&a.cell_idx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int idx = lds ? s_idx[k] : __hip_atomic_load(&a.cell_idx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (idx != 0x7fffffff) { a.sel[idx] = 1; ++got; }
         }
         if (got) atomicAdd(&s_round_sel, got);
