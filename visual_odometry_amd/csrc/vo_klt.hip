@@ -120,24 +120,24 @@ __device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin
 // one direction A -> B (N4).  returns flags: bit0 lost, bit1 flat at level 0.
 // Wave-uniform scalars (sub-pixel fractions, the 2x2 inverse, the running displacement) are pushed
 // back to SGPRs after every VALU step so that the register file holds little besides the template.
-template <class C>
+template <class C, bool SCORE>
 __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float* __restrict__ B, double su, double sv,
                       float* patch, int lane, int lbase, unsigned long long mask, double& qu, double& qv, float& ssd_out,
                       unsigned& iters, unsigned& setups) {
     constexpr int BW = C::BW, BH = C::BH, PW = C::PW;
-    float T[BH][BW], Tu[BH][BW], Tv[BH][BW];
+    // The residual sum is split, b = sum T*(Tu,Tv) - sum J*(Tu,Tv): the first term is a constant of the
+    // level, so the template intensities T never live in registers -- only the gradients do.
+    float Tu[BH][BW], Tv[BH][BW];
     const int ru = (a.wu - 1) / 2, rv = (a.wv - 1) / 2;
     const int nu0 = a.nu0, nv0 = a.nv0;
     double gu = 0, gv = 0;
     int flags = 0;
-    bool b0_staged = false; // the patch holds level 0 of image B at origin (b0_ou, b0_ov)
-    int b0_ou = 0, b0_ov = 0;
     for (int l = a.levels - 1; l >= 0; --l) {
         const double s = (double)(1 << l);
         int nu, nv; long lo;
         level_dims(nu0, nv0, l, nu, nv, lo);
         const double plu = su / s, plv = sv / s;
-        float sxx = 0, sxy = 0, syy = 0;
+        float sxx = 0, sxy = 0, syy = 0, ctu = 0, ctv = 0;
         {   // ---- template set-up: E = samples on the window grown by one pixel, Sobel/8 of E.
             // Rows stream through a 3-row ring so that only 3 x (BW+2) samples are live at a time.
             const double flu = floor(plu), flv = floor(plv);
@@ -166,16 +166,17 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                         const bool in = (mask >> (j * BW + i)) & 1ull;
                         const float tu = ((e0[i + 2] - e0[i]) + 2.0f * (e1[i + 2] - e1[i]) + (e2[i + 2] - e2[i])) * 0.125f;
                         const float tv = ((e2[i] - e0[i]) + 2.0f * (e2[i + 1] - e0[i + 1]) + (e2[i + 2] - e0[i + 2])) * 0.125f;
-                        T[j][i] = e1[i + 1];
                         Tu[j][i] = in ? tu : 0.0f;
                         Tv[j][i] = in ? tv : 0.0f;
                         sxx += Tu[j][i] * Tu[j][i]; sxy += Tu[j][i] * Tv[j][i]; syy += Tv[j][i] * Tv[j][i];
+                        ctu += e1[i + 1] * Tu[j][i]; ctv += e1[i + 1] * Tv[j][i];
                     }
                 }
             }
             ++setups;
         }
         const double Guu = (double)wave_sum(sxx), Guv = (double)wave_sum(sxy), Gvv = (double)wave_sum(syy);
+        const float CTu = wave_sum(ctu), CTv = wave_sum(ctv);
         const double dif = Guu - Gvv;
         const double mineig = ((Guu + Gvv) - sqrt(dif * dif + 4.0 * (Guv * Guv))) / (2.0 * (double)a.npx);
         const double det = Guu * Gvv - Guv * Guv;
@@ -208,7 +209,6 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                     stage<C>(patch, B + lo, nu, nv, pou, pov, lane);
                     staged = true;
                     fi = LK_M; fj = LK_M;
-                    if (l == 0) { b0_staged = true; b0_ou = pou; b0_ov = pov; }
                 }
                 const float fu = unif(tu - flu), fv = unif(tv - flv);
                 const int base = lbase + fj * PW + fi;
@@ -224,15 +224,15 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                     if (r > 0) {
 #pragma unroll
                         for (int c = 0; c < BW; ++c) {
-                            const float e = T[r - 1][c] - (hp[c] + fv * (p[c] - hp[c]));
-                            bu += e * Tu[r - 1][c];
-                            bv += e * Tv[r - 1][c];
+                            const float J = hp[c] + fv * (p[c] - hp[c]);
+                            bu += J * Tu[r - 1][c];
+                            bv += J * Tv[r - 1][c];
                         }
                     }
 #pragma unroll
                     for (int c = 0; c < BW; ++c) hp[c] = p[c];
                 }
-                const float Bu = wave_sum(bu), Bv = wave_sum(bv);
+                const float Bu = CTu - wave_sum(bu), Bv = CTv - wave_sum(bv);
                 ++iters;
                 const float ddu = unif(iuu * Bu + iuv * Bv);
                 const float ddv = unif(iuv * Bu + ivv * Bv);
@@ -249,16 +249,33 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
         if (!(qu >= 0.0 && qu <= (double)(nu0 - 1) && qv >= 0.0 && qv <= (double)(nv0 - 1))) flags |= 1;
     }
     ssd_out = 0.0f;
-    if (!(flags & 1)) { // N5 residual at level 0; T holds the level-0 template
-        const double flu = floor(qu), flv = floor(qv);
-        const int iu = uni((int)flu), iv = uni((int)flv);
-        int fi = iu - ru - b0_ou, fj = iv - rv - b0_ov;
-        if (!b0_staged || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) { // else reuse the last level-0 patch
-            stage<C>(patch, B, nu0, nv0, iu - ru - LK_M, iv - rv - LK_M, lane);
-            fi = LK_M; fj = LK_M;
+    if (SCORE && !(flags & 1)) { // N5 residual at level 0: re-sample the level-0 template, then the match
+        float T[BH][BW];
+        {
+            const double flu = floor(su), flv = floor(sv);
+            stage<C>(patch, A, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane);
+            const float fu = unif((float)(su - flu)), fv = unif((float)(sv - flv));
+            const int base = lbase + LK_M * PW + LK_M;
+            float hp[BW];
+#pragma unroll
+            for (int r = 0; r < BH + 1; ++r) {
+                float p[BW + 1];
+#pragma unroll
+                for (int c = 0; c < BW + 1; ++c) p[c] = patch[base + r * PW + c];
+#pragma unroll
+                for (int c = 0; c < BW; ++c) p[c] = p[c] + fu * (p[c + 1] - p[c]);
+                if (r > 0) {
+#pragma unroll
+                    for (int c = 0; c < BW; ++c) T[r - 1][c] = hp[c] + fv * (p[c] - hp[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < BW; ++c) hp[c] = p[c];
+            }
         }
+        const double flu = floor(qu), flv = floor(qv);
+        stage<C>(patch, B, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane);
         const float fu = unif((float)(qu - flu)), fv = unif((float)(qv - flv));
-        const int base = lbase + fj * PW + fi;
+        const int base = lbase + LK_M * PW + LK_M;
         float ssd = 0;
         float hp[BW];
 #pragma unroll
@@ -307,11 +324,11 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
     unsigned iters = 0, setups = 0;
     double fu, fv, bu = 0, bv = 0;
     float ssd, ssd2;
-    const int fl = lk_dir<C>(a, a.A, a.B, p0u, p0v, patch, lane, lbase, mask64, fu, fv, ssd, iters, setups);
+    const int fl = lk_dir<C, true>(a, a.A, a.B, p0u, p0v, patch, lane, lbase, mask64, fu, fv, ssd, iters, setups);
     bool ok = (fl == 0);
     float fb = __builtin_nanf("");
     if (!(fl & 1) && a.max_bidir >= 0.0) {
-        const int fl2 = lk_dir<C>(a, a.B, a.A, fu, fv, patch, lane, lbase, mask64, bu, bv, ssd2, iters, setups);
+        const int fl2 = lk_dir<C, false>(a, a.B, a.A, fu, fv, patch, lane, lbase, mask64, bu, bv, ssd2, iters, setups);
         if (fl2 & 1) ok = false;
         else {
             const double eu = p0u - bu, ev = p0v - bv;
