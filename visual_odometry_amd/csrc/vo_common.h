@@ -62,7 +62,7 @@ int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d
 struct vo_sel_work {       // device scratch of the selection pipeline
     double* resp; unsigned long long* maxbits; int32_t* blk_counts; int32_t* blk_offs;
     int32_t* lin; float* lu; float* lv; double* metric; uint8_t* keep; uint8_t* sel;
-    int32_t* m0; unsigned long long* cell_key; int32_t* cell_idx; int cap; int nblk;
+    int32_t* m0; unsigned long long* cell_key; int32_t* cell_idx; int32_t *klist, *kcell; int cap; int nblk;
     // uniform grid over the existing points (distance filter)
     float grid_cs; int grid_gu, grid_gv;
     int32_t *grid_count, *grid_cursor, *grid_offs, *grid_total; float *grid_su, *grid_sv;

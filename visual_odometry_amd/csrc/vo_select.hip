@@ -281,24 +281,44 @@ struct UniArgs {
     const float *cu, *cv; const double* metric; const int32_t* lin; const uint8_t* keep; uint8_t* sel;
     const int32_t* m0; int n_keep, nu, nv, u_is_rows;
     unsigned long long* cell_key; int32_t* cell_idx;
+    int32_t *klist, *kcell; // compact list of the kept corners and their cell in the current round
     float *out_u, *out_v; int32_t* out_lin; double* out_metric; int32_t* out_count;
 };
 
 constexpr int UNI_LDS_CELLS = 2048; // per-round cell tables live in LDS up to this many cells
 
+// floor((double)c * cells / n) without a division: the product is exact in double (24 + 13 bits),
+// a float estimate is corrected by exact integer-valued comparisons.  Identical to the oracle's
+// floor of the rounded quotient: a non-integer quotient of such operands stays > 2^-37 (relative)
+// away from any integer, far more than the 2^-53 rounding of the division.
+__device__ __forceinline__ int cell_exact(float c, int cells, int n, float inv_n) {
+    const double tt = (double)c * (double)cells;
+    int b = (int)floorf((float)tt * inv_n);
+    while ((double)(b + 1) * (double)n <= tt) ++b;
+    while ((double)b * (double)n > tt) --b;
+    return b;
+}
+
 __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
     __shared__ int s_cnt[16];
-    __shared__ int s_remaining, s_selected, s_round_sel;
+    __shared__ int s_remaining, s_selected, s_round_sel, s_nlist;
     __shared__ unsigned long long s_key[UNI_LDS_CELLS];
     __shared__ int s_idx[UNI_LDS_CELLS];
     const int t = threadIdx.x, m = *a.m0;
-    int loc = 0;
-    for (int i = t; i < m; i += 1024) { a.sel[i] = 0; loc += a.keep[i] ? 1 : 0; }
-    if (t == 0) { s_remaining = 0; s_selected = 0; }
+    if (t == 0) { s_nlist = 0; s_selected = 0; }
     __syncthreads();
-    if (loc) atomicAdd(&s_remaining, loc);
+    // compact the corners that survived the distance filter (order is irrelevant to the rounds)
+    for (int i = t; i < m; i += 1024) {
+        a.sel[i] = 0;
+        if (a.keep[i]) a.klist[atomicAdd(&s_nlist, 1)] = i;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int nl = s_nlist;
+    if (t == 0) s_remaining = nl;
     __syncthreads();
     const long H = a.u_is_rows ? a.nu : a.nv, W = a.u_is_rows ? a.nv : a.nu;
+    const float inv_nu = 1.0f / (float)a.nu, inv_nv = 1.0f / (float)a.nv;
     while (true) {
         const int selected = s_selected, remaining = s_remaining;
         if (!(selected < a.n_keep && remaining > 0)) break;
@@ -318,24 +338,24 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
         if (t == 0) s_round_sel = 0;
         __syncthreads();
         // phase 1: per-cell maximum metric (+1 so that a zero metric still differs from "empty")
-        for (int i = t; i < m; i += 1024) {
-            if (!a.keep[i] || a.sel[i]) continue;
-            int bu = (int)floor(((double)a.cu[i] * (double)cells_u) / (double)a.nu);
-            int bv = (int)floor(((double)a.cv[i] * (double)cells_v) / (double)a.nv);
-            bu = clampi(bu, 0, cells_u - 1); bv = clampi(bv, 0, cells_v - 1);
+        for (int e = t; e < nl; e += 1024) {
+            const int i = a.klist[e];
+            if (a.sel[i]) { a.kcell[e] = -1; continue; }
+            const int bu = clampi(cell_exact(a.cu[i], cells_u, a.nu, inv_nu), 0, cells_u - 1);
+            const int bv = clampi(cell_exact(a.cv[i], cells_v, a.nv, inv_nv), 0, cells_v - 1);
+            const int cell = bv * cells_u + bu;
+            a.kcell[e] = cell;
             const unsigned long long key = (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull;
-            if (lds) atomicMax(&s_key[bv * cells_u + bu], key);
-            else atomicMax(&a.cell_key[bv * cells_u + bu], key);
+            if (lds) atomicMax(&s_key[cell], key);
+            else atomicMax(&a.cell_key[cell], key);
         }
         __threadfence_block();
         __syncthreads();
         // phase 2: lowest index among the maxima
-        for (int i = t; i < m; i += 1024) {
-            if (!a.keep[i] || a.sel[i]) continue;
-            int bu = (int)floor(((double)a.cu[i] * (double)cells_u) / (double)a.nu);
-            int bv = (int)floor(((double)a.cv[i] * (double)cells_v) / (double)a.nv);
-            bu = clampi(bu, 0, cells_u - 1); bv = clampi(bv, 0, cells_v - 1);
-            const int cell = bv * cells_u + bu;
+        for (int e = t; e < nl; e += 1024) {
+            const int cell = a.kcell[e];
+            if (cell < 0) continue;
+            const int i = a.klist[e];
             const unsigned long long key = (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull;
             if (lds) { if (s_key[cell] == key) atomicMin(&s_idx[cell], i); }
             else if (__hip_atomic_load(&a.cell_key[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key)
@@ -349,6 +369,7 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
             if (idx != 0x7fffffff) { a.sel[idx] = 1; ++got; }
         }
         if (got) atomicAdd(&s_round_sel, got);
+        __threadfence_block();
         __syncthreads();
         if (t == 0) { s_selected += s_round_sel; s_remaining -= s_round_sel; }
         __syncthreads();
@@ -533,7 +554,7 @@ int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is
     UniArgs a;
     a.cu = w->lu; a.cv = w->lv; a.metric = w->metric; a.lin = w->lin; a.keep = w->keep; a.sel = w->sel; a.m0 = w->m0;
     a.n_keep = o->keep; a.nu = nu; a.nv = nv; a.u_is_rows = u_is_rows;
-    a.cell_key = w->cell_key; a.cell_idx = w->cell_idx;
+    a.cell_key = w->cell_key; a.cell_idx = w->cell_idx; a.klist = w->klist; a.kcell = w->kcell;
     a.out_u = d_out_u; a.out_v = d_out_v; a.out_lin = d_out_lin; a.out_metric = d_out_metric; a.out_count = d_out_count;
     hipLaunchKernelGGL(k_uniform, dim3(1), dim3(1024), 0, ctx->stream, a);
     VO_HIP_CHECK(ctx, hipGetLastError());
