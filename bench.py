@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = the hot path of one VO frame with every input resident in HBM (visual_odometry_amd/
-device.py): pyramid build, KLT track of the landmark and candidate keypoints, P3P-RANSAC pose,
+device.py): pyramid build, KLT track of the landmark and candidate keypoints (one launch), P3P-RANSAC pose,
 batched triangulation, candidate selection.  Default workload = BASELINE.json configs[3] (synthetic
 1241x376, 50k keypoints per frame split into 25k landmarks + 25k candidates, 4 levels, 2k RANSAC
 hypotheses) -- the configuration the north-star target is quoted on.  N > 1: every rank runs its own
@@ -110,23 +110,31 @@ def main():
         a, b = wl.k % 2, (wl.k + 1) % 2
         wl.build(b, (wl.k % wl.n_frames) + 1)
         reps = 20
-        wl.track_landmarks(a, b); wl.sync()
+        wl.track_all(a, b); wl.sync()
         ctx.counters(reset=True)
         ctx.timer_start()
         for _ in range(reps):
-            wl.track_landmarks(a, b)
+            wl.track_all(a, b)
         ms = ctx.timer_stop_ms() / reps
         it, kp, su, _ = ctx.counters(reset=True)
         flops = WINDOW_PX * (FLOP_ITER_PX * it + FLOP_SETUP_PX * su) / reps
         ach = flops / (ms * 1e-3) / 1e12
+        traffic = None
+        try:  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same kernel / workload
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_k_lk_pmc.json")))
+            if pmc.get("keypoints_per_launch") == args.keypoints:
+                traffic = pmc["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         roof = {"bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
-                "traffic": None, "kernel": "k_lk<41x41>", "launch_ms": ms, "keypoints_per_launch": nl,
+                "traffic": traffic, "kernel": "k_lk<41x41>", "launch_ms": ms, "keypoints_per_launch": args.keypoints,
                 "iters_per_keypoint": it / max(kp, 1), "setups_per_keypoint": su / max(kp, 1),
                 "note": "fp32 VALU-bound kernel, no MFMA used (nothing here is a dense contraction); peak = fp32 "
-                        "vector rate = fp32-input MFMA rate; flops = 1681 px x (11/iteration + 24/set-up), SURVEY 8d"}
-        for name, fn in (("pyramid", lambda: wl.build(b, (wl.k % wl.n_frames) + 1)), ("klt_landmarks", lambda: wl.track_landmarks(a, b)),
-                         ("klt_candidates", lambda: wl.track_candidates(a, b)), ("ransac", wl.pose),
-                         ("triangulate", wl.triangulate), ("select", lambda: wl.select(1))):
+                        "vector rate = fp32-input MFMA rate; flops = 1681 px x (11/iteration + 24/set-up), SURVEY 8d; "
+                        "traffic = (FETCH_SIZE + WRITE_SIZE) x 1024 per launch from profiles/round1_k_lk_pmc.json "
+                        "(fabric-side, Infinity-Cache hits included, 4-B/lane pattern uncalibrated)"}
+        for name, fn in (("pyramid", lambda: wl.build(b, (wl.k % wl.n_frames) + 1)), ("klt_landmarks+candidates", lambda: wl.track_all(a, b)),
+                         ("ransac", wl.pose), ("triangulate", wl.triangulate), ("select", lambda: wl.select(1))):
             fn(); wl.sync()
             ctx.timer_start()
             for _ in range(5):

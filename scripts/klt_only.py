@@ -5,7 +5,7 @@ sys.path.insert(0, ".")
 import torch
 from visual_odometry_amd import _lib
 from visual_odometry_amd.device import FrameWorkload
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 25000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 ctx = _lib.Context(0)
 wl = FrameWorkload(ctx, n, 16, n_frames=2, num_hyp=8)

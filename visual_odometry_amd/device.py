@@ -36,12 +36,16 @@ class FrameWorkload:
             u, v = synth.keypoints(n, nv, nu, seed=sd)
             return torch.from_numpy(np.stack([u, v])).to(self.dev).contiguous()       # SoA 2 x n
 
-        self.pl, self.pc = pts(self.nl, seed + 1024), pts(self.nc, seed + 2048)
-        self.ql, self.qc = torch.empty_like(self.pl), torch.empty_like(self.pc)
-        self.vl = torch.empty(self.nl, dtype=torch.uint8, device=self.dev)
-        self.vc = torch.empty(self.nc, dtype=torch.uint8, device=self.dev)
-        self.sl = torch.empty(self.nl, dtype=torch.float32, device=self.dev)
-        self.sc = torch.empty(self.nc, dtype=torch.float32, device=self.dev)
+        # landmark and candidate keypoints live back to back so that the frame's two track calls
+        # (modules/VisualOdometry.m:278 and :71) can be issued as ONE launch over both sets
+        self.pa = torch.cat([pts(self.nl, seed + 1024), pts(self.nc, seed + 2048)], 1).contiguous()
+        self.qa = torch.empty_like(self.pa)
+        self.va = torch.empty(self.nl + self.nc, dtype=torch.uint8, device=self.dev)
+        self.sa = torch.empty(self.nl + self.nc, dtype=torch.float32, device=self.dev)
+        self.pl, self.pc = self.pa[:, :self.nl], self.pa[:, self.nl:]
+        self.ql, self.qc = self.qa[:, :self.nl], self.qa[:, self.nl:]
+        self.vl, self.vc = self.va[:self.nl], self.va[self.nl:]
+        self.sl, self.sc = self.sa[:self.nl], self.sa[self.nl:]
         # pose step: landmarks + observations
         xy, X, *_ = synth.pnp_scene(self.nl, seed=seed + 3072, nv=nv, nu=nu)
         self.rs_xy = torch.from_numpy(xy).to(self.dev); self.rs_X = torch.from_numpy(X).to(self.dev)
@@ -60,7 +64,7 @@ class FrameWorkload:
         self.tr_rep = torch.empty(self.nc, **f64); self.tr_ang = torch.empty(self.nc, **f64)
         self.tr_val = torch.empty(self.nc, dtype=torch.uint8, device=self.dev)
         # selection against every tracked point
-        ex = torch.cat([self.pl, self.pc], 1).to(torch.float32).contiguous()
+        ex = self.pa.to(torch.float32).contiguous()
         self.ex = ex; self.n_exist = ex.shape[1]
         self.sel_opts = SelOpts(7.0, 0.001, 5, int(keep), _lib.SCORER_MINEIGEN, 0.08)
         self.sel_u = torch.empty(max(keep, 1), dtype=torch.float32, device=self.dev)
@@ -79,6 +83,9 @@ class FrameWorkload:
         n = p.shape[1]
         self.ctx.call("vo_dev_klt_track", a, b, _p(p[0]), _p(p[1]), n, self.block, self.block, self.max_iters,
                       C.c_double(self.eps), C.c_double(self.max_bidir), _p(q[0]), _p(q[1]), _p(valid), _p(score), None)
+
+    def track_all(self, a, b):
+        self.track(a, b, self.pa, self.qa, self.va, self.sa)
 
     def track_landmarks(self, a, b):
         self.track(a, b, self.pl, self.ql, self.vl, self.sl)
@@ -106,10 +113,9 @@ class FrameWorkload:
         a, b = k % 2, (k + 1) % 2
         nxt = (k % self.n_frames) + 1
         self.build(b, nxt)
-        self.track_landmarks(a, b)
+        self.track_all(a, b)       # landmarks + candidates in one launch
         if self.nl >= 4:
             self.pose()
-        self.track_candidates(a, b)
         self.triangulate()
         self.select(nxt)
         self.k += 1
