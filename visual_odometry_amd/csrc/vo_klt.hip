@@ -6,12 +6,15 @@
 // pass.  The wu x wv window is cut into LU x LV rectangular blocks of BW x BH pixels, one block per
 // lane, so that a lane's bilinear taps overlap: (BW+1)(BH+1) LDS reads serve BW*BH pixels (1.4
 // reads/pixel for the 41x41 window instead of 4) and the interpolation is separable in registers.
-// The template (T, Tu, Tv) lives in registers for a whole level; the gradients are the Sobel/8
+// The template gradients (Tu, Tv) live in registers for a whole level; they are the Sobel/8
 // operator applied to the sub-pixel-sampled template itself, so a frame's pyramid is ONE float
-// plane per level.  The search patch of the other image is staged into LDS once per level with a
-// margin of LK_M pixels and re-staged only when the estimate walks out of it: an iteration touches
-// nothing but LDS and registers.  Patch pitches are chosen so that the 32-lane halves of a wave hit
-// distinct banks (at most 2-way on a handful of lanes).  Wave sums use DPP row operations.
+// plane per level.  The template intensities are not kept: the residual sum splits into
+// b = sum T*g - sum J*g, and the first term is a per-level constant computed during set-up.
+// The search patch of the other image is staged into LDS once per level (LDS-DMA, one patch row
+// per wave instruction) with a margin of LK_M pixels and re-staged only when the estimate walks
+// out of it: an iteration touches nothing but LDS and registers.  Patch pitches are chosen so that
+// the 32-lane halves of a wave hit distinct banks (at most 2-way on a handful of lanes).  Wave
+// sums use DPP row operations.
 //
 // Bound: FP32 VALU (+ LDS bandwidth); HBM traffic is the pyramids only (L2 / Infinity Cache hits).
 // Algorithmic flops: set-up 24 flop/px, iteration 11 flop/px; ctx counters [0] and [2]
