@@ -126,7 +126,7 @@ __device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin
 template <class C, bool SCORE>
 __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float* __restrict__ B, double su, double sv,
                       float* patch, int lane, int lbase, unsigned long long mask, double& qu, double& qv, float& ssd_out,
-                      unsigned& iters, unsigned& setups) {
+                      unsigned& iters, unsigned& setups, unsigned& cells) {
     constexpr int BW = C::BW, BH = C::BH, PW = C::PW;
     // The residual sum is split, b = sum T*(Tu,Tv) - sum J*(Tu,Tv): the first term is a constant of the
     // level, so the template intensities T never live in registers -- only the gradients do.
@@ -195,8 +195,12 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             const int ibu = uni((int)fbu0), ibv = uni((int)fbv0);
             const float fbu = unif((float)(bu0 - fbu0)), fbv = unif((float)(bv0 - fbv0));
             const float sf = (float)(1 << l), umax = (float)(nu0 - 1), vmax = (float)(nv0 - 1);
-            bool staged = false;
-            int pou = 0, pov = 0;
+            bool staged = false, cell = false;
+            int pou = 0, pov = 0, ciu = 0, civ = 0;
+            // sum J*(Tu,Tv) is bilinear in the sub-pixel fractions: inside one pixel cell it is the
+            // interpolation of the four integer-offset correlations c[dv][du] = sum P(x+du, y+dv)*(Tu,Tv).
+            // They are computed once per visited cell; an iteration inside the cell is scalar work.
+            float cu00 = 0, cu10 = 0, cu01 = 0, cu11 = 0, cv00 = 0, cv10 = 0, cv01 = 0, cv11 = 0;
             for (int it = 0; it < a.max_iters; ++it) {
                 const float tu = fbu + du, tv = fbv + dv;
                 const float cu0 = ((float)ibu + tu) * sf, cv0 = ((float)ibv + tv) * sf; // level-0 position (N4 lost test)
@@ -206,36 +210,45 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                 }
                 const float flu = floorf(tu), flv = floorf(tv);
                 const int iu = ibu + uni((int)flu), iv = ibv + uni((int)flv);
-                int fi = iu - ru - pou, fj = iv - rv - pov;
-                if (!staged || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) {
-                    pou = iu - ru - LK_M; pov = iv - rv - LK_M;
-                    stage<C>(patch, B + lo, nu, nv, pou, pov, lane);
-                    staged = true;
-                    fi = LK_M; fj = LK_M;
-                }
-                const float fu = unif(tu - flu), fv = unif(tv - flv);
-                const int base = lbase + fj * PW + fi;
-                float bu = 0, bv = 0;
-                float hp[BW];
+                if (!cell || iu != ciu || iv != civ) {
+                    int fi = iu - ru - pou, fj = iv - rv - pov;
+                    if (!staged || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) {
+                        pou = iu - ru - LK_M; pov = iv - rv - LK_M;
+                        stage<C>(patch, B + lo, nu, nv, pou, pov, lane);
+                        staged = true;
+                        fi = LK_M; fj = LK_M;
+                    }
+                    const int base = lbase + fj * PW + fi;
+                    float su00 = 0, su10 = 0, su01 = 0, su11 = 0, sv00 = 0, sv10 = 0, sv01 = 0, sv11 = 0;
 #pragma unroll
-                for (int r = 0; r < BH + 1; ++r) {
-                    float p[BW + 1];
+                    for (int r = 0; r < BH + 1; ++r) {
+                        float p[BW + 1];
 #pragma unroll
-                    for (int c = 0; c < BW + 1; ++c) p[c] = patch[base + r * PW + c];
+                        for (int c = 0; c < BW + 1; ++c) p[c] = patch[base + r * PW + c];
+                        if (r < BH) {
 #pragma unroll
-                    for (int c = 0; c < BW; ++c) p[c] = p[c] + fu * (p[c + 1] - p[c]);
-                    if (r > 0) {
+                            for (int c = 0; c < BW; ++c) {
+                                su00 += p[c] * Tu[r][c]; su10 += p[c + 1] * Tu[r][c];
+                                sv00 += p[c] * Tv[r][c]; sv10 += p[c + 1] * Tv[r][c];
+                            }
+                        }
+                        if (r > 0) {
 #pragma unroll
-                        for (int c = 0; c < BW; ++c) {
-                            const float J = hp[c] + fv * (p[c] - hp[c]);
-                            bu += J * Tu[r - 1][c];
-                            bv += J * Tv[r - 1][c];
+                            for (int c = 0; c < BW; ++c) {
+                                su01 += p[c] * Tu[r - 1][c]; su11 += p[c + 1] * Tu[r - 1][c];
+                                sv01 += p[c] * Tv[r - 1][c]; sv11 += p[c + 1] * Tv[r - 1][c];
+                            }
                         }
                     }
-#pragma unroll
-                    for (int c = 0; c < BW; ++c) hp[c] = p[c];
+                    cu00 = wave_sum(su00); cu10 = wave_sum(su10); cu01 = wave_sum(su01); cu11 = wave_sum(su11);
+                    cv00 = wave_sum(sv00); cv10 = wave_sum(sv10); cv01 = wave_sum(sv01); cv11 = wave_sum(sv11);
+                    cell = true; ciu = iu; civ = iv;
+                    ++cells;
                 }
-                const float Bu = CTu - wave_sum(bu), Bv = CTv - wave_sum(bv);
+                const float fu = unif(tu - flu), fv = unif(tv - flv);
+                const float hu0 = cu00 + fu * (cu10 - cu00), hu1 = cu01 + fu * (cu11 - cu01);
+                const float hv0 = cv00 + fu * (cv10 - cv00), hv1 = cv01 + fu * (cv11 - cv01);
+                const float Bu = CTu - (hu0 + fv * (hu1 - hu0)), Bv = CTv - (hv0 + fv * (hv1 - hv0));
                 ++iters;
                 const float ddu = unif(iuu * Bu + iuv * Bv);
                 const float ddv = unif(iuv * Bu + ivv * Bv);
@@ -324,14 +337,14 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
                 if (lu * C::BW + i < a.wu && lv * C::BH + j < a.wv) mask64 |= 1ull << (j * C::BW + i);
     }
     const double p0u = a.pu[kp], p0v = a.pv[kp];
-    unsigned iters = 0, setups = 0;
+    unsigned iters = 0, setups = 0, cells = 0;
     double fu, fv, bu = 0, bv = 0;
     float ssd, ssd2;
-    const int fl = lk_dir<C, true>(a, a.A, a.B, p0u, p0v, patch, lane, lbase, mask64, fu, fv, ssd, iters, setups);
+    const int fl = lk_dir<C, true>(a, a.A, a.B, p0u, p0v, patch, lane, lbase, mask64, fu, fv, ssd, iters, setups, cells);
     bool ok = (fl == 0);
     float fb = __builtin_nanf("");
     if (!(fl & 1) && a.max_bidir >= 0.0) {
-        const int fl2 = lk_dir<C, false>(a, a.B, a.A, fu, fv, patch, lane, lbase, mask64, bu, bv, ssd2, iters, setups);
+        const int fl2 = lk_dir<C, false>(a, a.B, a.A, fu, fv, patch, lane, lbase, mask64, bu, bv, ssd2, iters, setups, cells);
         if (fl2 & 1) ok = false;
         else {
             const double eu = p0u - bu, ev = p0v - bv;
@@ -354,6 +367,9 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
         atomicAdd(&cnt[0], (unsigned long long)iters);
         atomicAdd(&cnt[1], 1ull);
         atomicAdd(&cnt[2], (unsigned long long)setups);
+#ifdef VO_KLT_COUNT_CELLS // profiling builds only: slot 3 belongs to the pose step's hypothesis count
+        atomicAdd(&cnt[3], (unsigned long long)cells);
+#endif
     }
 }
 
