@@ -45,13 +45,15 @@ struct Cfg {
     static constexpr bool COL = COL_;
     static constexpr int PH = LV * BH + 1 + 2 * LK_M;
     static constexpr int MAXU = LU * BW, MAXV = LV * BH;
+    static constexpr int NQ = PW / 4, RPI = 64 / NQ; // 16-byte pieces per patch row, rows per LDS-DMA instruction
+    static_assert(PW % 4 == 0, "patch pitch must be a multiple of 4 (16-byte LDS-DMA rows)");
     static_assert(PW >= LU * BW + 1 + 2 * LK_M, "patch pitch too small");
     static_assert(LU * LV <= 64, "more blocks than lanes");
 };
 // pitches from a bank-conflict search over (lane -> block) orders, see DESIGN.md
-using CfgS = Cfg<3, 3, 7, 7, 39, false, 5>;  // windows up to 21 x 21
-using CfgM = Cfg<5, 4, 7, 8, 43, true, 4>;   // up to 35 x 32
-using CfgL = Cfg<6, 5, 7, 9, 49, false, 4>;  // up to 42 x 45 (the reference's 41 x 41)
+using CfgS = Cfg<3, 3, 7, 7, 28, true, 5>;   // windows up to 21 x 21
+using CfgM = Cfg<5, 4, 7, 8, 44, false, 4>;  // up to 35 x 32
+using CfgL = Cfg<5, 6, 9, 7, 52, false, 4>;  // up to 45 x 42 (the reference's 41 x 41)
 using CfgX = Cfg<7, 7, 8, 8, 68, true, 1>;   // up to 56 x 56 (51 x 51 of module_tests/updateW2D3D_test.m:20)
 
 __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
@@ -88,24 +90,43 @@ typedef __attribute__((address_space(1))) const float glb_float;
 
 template <class C>
 __device__ __forceinline__ void stage(float* patch, const float* __restrict__ img, int nu, int nv, int ou, int ov,
-                                      int lane) {
+                                      int lane, int lr, int lq) {
+#if defined(__HIP_DEVICE_COMPILE__) // the host pass cannot type-check the 16-byte LDS-DMA builtin
     __syncthreads();
-    // LDS-DMA: each wave-instruction moves one patch row (lane = column) straight into LDS; no VGPR
-    // staging, every row in flight at once.  LDS address = M0 base (the row) + lane * 4.
     lds_float* lp = reinterpret_cast<lds_float*>(reinterpret_cast<uintptr_t>(patch));
+    if (ou >= 0 && ou + C::PW <= nu) {
+        // Columns inside the image (wave-uniform): 16-byte LDS-DMA.  The LDS image is lane-linear per
+        // instruction (base + lane * 16), so with PW a multiple of 4 lanes (lr, lq) = (lane / NQ, lane % NQ)
+        // fill RPI whole rows per instruction from per-lane source addresses that need only 4-byte
+        // alignment (scripts/ubench/glds16.hip).  Rows are replicate-clamped per lane.
+        constexpr int NQ = C::NQ, RPI = C::RPI, NI = (C::PH + RPI - 1) / RPI;
+        if (lane < RPI * NQ) {
+            if (ov >= 0 && ov + C::PH <= nv) { // rows inside too: the per-lane address just advances
+                const float* g = img + ((long)(ov + lr) * nu + (ou + 4 * lq));
 #pragma unroll
-    for (int c0 = 0; c0 < C::PW; c0 += 64) {
-        const int c = c0 + lane;
-        if (c < C::PW) {
-            const int cc = clampi(ou + c, 0, nu - 1);
-            if (ov >= 0 && ov + C::PH <= nv) { // interior rows (wave-uniform): the row base just advances
-                const float* rowp = img + (long)ov * nu;
-#pragma unroll
-                for (int r = 0; r < C::PH; ++r) {
-                    __builtin_amdgcn_global_load_lds((glb_float*)(rowp + cc), lp + r * C::PW + c0, 4, 0, 0);
-                    rowp += nu;
+                for (int k = 0; k < NI; ++k) {
+                    if ((k + 1) * RPI <= C::PH || lr < C::PH - k * RPI)
+                        __builtin_amdgcn_global_load_lds((glb_float*)g, lp + k * RPI * C::PW, 16, 0, 0);
+                    g += RPI * nu;
                 }
             } else {
+                const unsigned col = (unsigned)(ou + 4 * lq); // a level has fewer than 2^24 rows / columns
+#pragma unroll
+                for (int k = 0; k < NI; ++k) {
+                    const unsigned row = (unsigned)clampi(ov + lr + k * RPI, 0, nv - 1);
+                    const unsigned off = __umul24(row, (unsigned)nu) + col;
+                    if ((k + 1) * RPI <= C::PH || lr < C::PH - k * RPI)
+                        __builtin_amdgcn_global_load_lds((glb_float*)(img + off), lp + k * RPI * C::PW, 16, 0, 0);
+                }
+            }
+        }
+    } else {
+        // a column border crosses the patch: 4-byte LDS-DMA, lane = patch column, columns clamped per lane
+#pragma unroll
+        for (int c0 = 0; c0 < C::PW; c0 += 64) {
+            const int c = c0 + lane;
+            if (c < C::PW) {
+                const int cc = clampi(ou + c, 0, nu - 1);
 #pragma unroll
                 for (int r = 0; r < C::PH; ++r) {
                     const float* rowp = img + (long)clampi(ov + r, 0, nv - 1) * nu;
@@ -116,6 +137,7 @@ __device__ __forceinline__ void stage(float* patch, const float* __restrict__ im
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#endif
 }
 
 __device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
@@ -125,7 +147,7 @@ __device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin
 // back to SGPRs after every VALU step so that the register file holds little besides the template.
 template <class C, bool SCORE>
 __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float* __restrict__ B, double su, double sv,
-                      float* patch, int lane, int lbase, unsigned long long mask, double& qu, double& qv, float& ssd_out,
+                      float* patch, int lane, int lr, int lq, int lbase, unsigned long long mask, double& qu, double& qv, float& ssd_out,
                       unsigned& iters, unsigned& setups, unsigned& cells) {
     constexpr int BW = C::BW, BH = C::BH, PW = C::PW;
     // The residual sum is split, b = sum T*(Tu,Tv) - sum J*(Tu,Tv): the first term is a constant of the
@@ -145,7 +167,11 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             // Rows stream through a 3-row ring so that only 3 x (BW+2) samples are live at a time.
             const double flu = floor(plu), flv = floor(plv);
             const float fu = unif((float)(plu - flu)), fv = unif((float)(plv - flv));
-            stage<C>(patch, A + lo, nu, nv, uni((int)flu) - ru - 1, uni((int)flv) - rv - 1, lane);
+            stage<C>(patch, A + lo, nu, nv, uni((int)flu) - ru - 1, uni((int)flv) - rv - 1, lane, lr, lq);
+            // E rows stream through a 3-row ring.  Separable Sobel per template row: VD = vertical
+            // difference, VS = vertical 1-2-1 smoothing of the three rows, then the horizontal halves.
+            // Gradients are kept times 8 (the 1/8 of the operator is a power of two: it is folded,
+            // exactly, into G and the 2x2 inverse below).
             float E[3][BW + 2];
             float hp[BW + 2];
 #pragma unroll
@@ -164,11 +190,17 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                 if (r >= 3) { // E rows j, j+1, j+2 are complete: emit template row j
                     const int j = r - 3;
                     const float* e0 = E[j % 3]; const float* e1 = E[(j + 1) % 3]; const float* e2 = E[(j + 2) % 3];
+                    float VD[BW + 2], VS[BW + 2];
+#pragma unroll
+                    for (int c = 0; c < BW + 2; ++c) {
+                        VD[c] = e2[c] - e0[c];
+                        VS[c] = (e0[c] + 2.0f * e1[c]) + e2[c];
+                    }
 #pragma unroll
                     for (int i = 0; i < BW; ++i) {
                         const bool in = (mask >> (j * BW + i)) & 1ull;
-                        const float tu = ((e0[i + 2] - e0[i]) + 2.0f * (e1[i + 2] - e1[i]) + (e2[i + 2] - e2[i])) * 0.125f;
-                        const float tv = ((e2[i] - e0[i]) + 2.0f * (e2[i + 1] - e0[i + 1]) + (e2[i + 2] - e0[i + 2])) * 0.125f;
+                        const float tu = VS[i + 2] - VS[i];
+                        const float tv = (VD[i] + 2.0f * VD[i + 1]) + VD[i + 2];
                         Tu[j][i] = in ? tu : 0.0f;
                         Tv[j][i] = in ? tv : 0.0f;
                         sxx += Tu[j][i] * Tu[j][i]; sxy += Tu[j][i] * Tv[j][i]; syy += Tv[j][i] * Tv[j][i];
@@ -178,7 +210,8 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             }
             ++setups;
         }
-        const double Guu = (double)wave_sum(sxx), Guv = (double)wave_sum(sxy), Gvv = (double)wave_sum(syy);
+        // sums of the x8 gradients: G = sums / 64
+        const double Guu = (double)wave_sum(sxx) * 0.015625, Guv = (double)wave_sum(sxy) * 0.015625, Gvv = (double)wave_sum(syy) * 0.015625;
         const float CTu = wave_sum(ctu), CTv = wave_sum(ctv);
         const double dif = Guu - Gvv;
         const double mineig = ((Guu + Gvv) - sqrt(dif * dif + 4.0 * (Guv * Guv))) / (2.0 * (double)a.npx);
@@ -188,7 +221,8 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
         if (flat) {
             if (l == 0) flags |= 2;
         } else {
-            const float iuu = unif((float)(Gvv / det)), iuv = unif((float)(-Guv / det)), ivv = unif((float)(Guu / det));
+            // the residual sums carry the x8 of the gradients: 1/8 goes into the inverse
+            const float iuu = unif((float)(Gvv / det) * 0.125f), iuv = unif((float)(-Guv / det) * 0.125f), ivv = unif((float)(Guu / det) * 0.125f);
             // position = (ibu + fbu + du, ibv + fbv + dv): integer base + float remainder
             const double bu0 = plu + gu, bv0 = plv + gv;
             const double fbu0 = floor(bu0), fbv0 = floor(bv0);
@@ -214,7 +248,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                     int fi = iu - ru - pou, fj = iv - rv - pov;
                     if (!staged || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) {
                         pou = iu - ru - LK_M; pov = iv - rv - LK_M;
-                        stage<C>(patch, B + lo, nu, nv, pou, pov, lane);
+                        stage<C>(patch, B + lo, nu, nv, pou, pov, lane, lr, lq);
                         staged = true;
                         fi = LK_M; fj = LK_M;
                     }
@@ -269,7 +303,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
         float T[BH][BW];
         {
             const double flu = floor(su), flv = floor(sv);
-            stage<C>(patch, A, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane);
+            stage<C>(patch, A, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane, lr, lq);
             const float fu = unif((float)(su - flu)), fv = unif((float)(sv - flv));
             const int base = lbase + LK_M * PW + LK_M;
             float hp[BW];
@@ -289,7 +323,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             }
         }
         const double flu = floor(qu), flv = floor(qv);
-        stage<C>(patch, B, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane);
+        stage<C>(patch, B, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane, lr, lq);
         const float fu = unif((float)(qu - flu)), fv = unif((float)(qv - flv));
         const int base = lbase + LK_M * PW + LK_M;
         float ssd = 0;
@@ -319,8 +353,9 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
 
 template <class C>
 __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
-    __shared__ float patch[C::PW * C::PH];
+    __shared__ __attribute__((aligned(16))) float patch[C::PW * C::PH];
     const int lane = threadIdx.x, kp = blockIdx.x;
+    const int lr = lane / C::NQ, lq = lane - lr * C::NQ; // this lane's (row, 16-byte piece) in a staging instruction
     // lane -> block; lanes beyond LU*LV read block 0's pixels with an all-masked window
     int lu, lv;
     const bool live = lane < C::LU * C::LV;
@@ -340,11 +375,11 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
     unsigned iters = 0, setups = 0, cells = 0;
     double fu, fv, bu = 0, bv = 0;
     float ssd, ssd2;
-    const int fl = lk_dir<C, true>(a, a.A, a.B, p0u, p0v, patch, lane, lbase, mask64, fu, fv, ssd, iters, setups, cells);
+    const int fl = lk_dir<C, true>(a, a.A, a.B, p0u, p0v, patch, lane, lr, lq, lbase, mask64, fu, fv, ssd, iters, setups, cells);
     bool ok = (fl == 0);
     float fb = __builtin_nanf("");
     if (!(fl & 1) && a.max_bidir >= 0.0) {
-        const int fl2 = lk_dir<C, false>(a, a.B, a.A, fu, fv, patch, lane, lbase, mask64, bu, bv, ssd2, iters, setups, cells);
+        const int fl2 = lk_dir<C, false>(a, a.B, a.A, fu, fv, patch, lane, lr, lq, lbase, mask64, bu, bv, ssd2, iters, setups, cells);
         if (fl2 & 1) ok = false;
         else {
             const double eu = p0u - bu, ev = p0v - bv;
