@@ -234,15 +234,27 @@ static inline void bearing(const double* K, double u, double v, double* f) {
     f[0] = x / n; f[1] = y / n; f[2] = 1.0 / n;
 }
 
-/* squared reprojection error of X under (R_cw, t_cw), fixed operation order */
-static inline double reproj_e2(const double* R, const double* t, const double* K, const double* X, const double* xy) {
-    double xc = ((R[0] * X[0] + R[1] * X[1]) + R[2] * X[2]) + t[0];
-    double yc = ((R[3] * X[0] + R[4] * X[1]) + R[5] * X[2]) + t[1];
-    double zc = ((R[6] * X[0] + R[7] * X[1]) + R[8] * X[2]) + t[2];
-    double up = (K[0] * xc + K[1] * yc) + K[2] * zc;
-    double vp = K[4] * yc + K[5] * zc;
-    double du = xy[0] - up / zc, dv = xy[1] - vp / zc;
-    return du * du + dv * dv;
+/* N9 scoring.  Each pose (R_cw row-major, t_cw) is folded once into the 3x4 projection
+ * Pm = K [R_cw | t_cw]; the projection stays homogeneous, so the inlier test needs no division:
+ * ez = (u*z - u~)^2 + (v*z - v~)^2 < thr^2 * z^2.  Explicit fused multiply-adds in a fixed order
+ * (fma() is correctly rounded on every platform); only inliers pay for e2 = ez / z^2.  Equivalent to
+ * errors = sum((p - proj).^2) < tol^2 of old/ransacLocalization.m:96-99 up to rounding at the
+ * threshold. */
+static void proj_matrix(const double* Rt, const double* K, double* P) {
+    for (int c = 0; c < 4; ++c) {
+        const double g0 = c < 3 ? Rt[c] : Rt[9], g1 = c < 3 ? Rt[3 + c] : Rt[10], g2 = c < 3 ? Rt[6 + c] : Rt[11];
+        P[c] = fma(K[2], g2, fma(K[1], g1, K[0] * g0));
+        P[4 + c] = fma(K[5], g2, K[4] * g1);
+        P[8 + c] = g2;
+    }
+}
+static inline void proj_terms(const double* P, const double* X, const double* xy, double* ez, double* z2) {
+    const double up = fma(P[2], X[2], fma(P[1], X[1], fma(P[0], X[0], P[3])));
+    const double vp = fma(P[6], X[2], fma(P[5], X[1], fma(P[4], X[0], P[7])));
+    const double zc = fma(P[10], X[2], fma(P[9], X[1], fma(P[8], X[0], P[11])));
+    const double du = fma(xy[0], zc, -up), dv = fma(xy[1], zc, -vp);
+    *ez = fma(dv, dv, du * du);
+    *z2 = zc * zc;
 }
 
 int vo_or_p3p_ransac(const double* xy, const double* X, int m, const double* K, const vo_or_ransac_opts* o,
@@ -281,9 +293,12 @@ int vo_or_p3p_ransac(const double* xy, const double* X, int m, const double* K, 
                 for (int c = 0; c < 3; ++c) R[r * 3 + c] = Rwc[c * 3 + r];          /* :66 */
             for (int r = 0; r < 3; ++r) t[r] = -((R[r * 3] * C[0] + R[r * 3 + 1] * C[1]) + R[r * 3 + 2] * C[2]); /* :67 */
             int c_ = 0; uint64_t q = 0;
+            double Pm[12];
+            proj_matrix(R, K, Pm);
             for (int i = 0; i < m; ++i) {
-                double e2 = reproj_e2(R, t, K, X + 3 * i, xy + 2 * i);
-                if (e2 < thr2) { ++c_; q += (uint64_t)(e2 * 1048576.0); } else q += qthr;
+                double ez, z2;
+                proj_terms(Pm, X + 3 * i, xy + 2 * i, &ez, &z2);
+                if (ez < thr2 * z2) { ++c_; q += (uint64_t)((ez / z2) * 1048576.0); } else q += qthr;
             }
             cnt[4 * h + s] = c_; cost[4 * h + s] = q;
         }
@@ -316,7 +331,13 @@ int vo_or_p3p_ransac(const double* xy, const double* X, int m, const double* K, 
     if (bh >= 0) {
         const double* R = Rt + 48 * (size_t)bh + 12 * bs; const double* t = R + 9;
         memcpy(Rout, R, 72); memcpy(tout, t, 24);
-        for (int i = 0; i < m; ++i) inliers[i] = (uint8_t)(reproj_e2(R, t, K, X + 3 * i, xy + 2 * i) < thr2);
+        double Pm[12];
+        proj_matrix(R, K, Pm);
+        for (int i = 0; i < m; ++i) {
+            double ez, z2;
+            proj_terms(Pm, X + 3 * i, xy + 2 * i, &ez, &z2);
+            inliers[i] = (uint8_t)(ez < thr2 * z2);
+        }
         if (best_hyp) *best_hyp = bh;
         if (best_sol) *best_sol = bs;
         status = 0;

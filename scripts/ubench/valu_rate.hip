@@ -8,6 +8,7 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float a, float b)
     float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
     float2v p0 = {x0, x1}, p1 = {x2, x3}, p2 = {x4, x5}, p3 = {x6, x7}, p4 = {x1, x0}, p5 = {x3, x2}, p6 = {x5, x4}, p7 = {x7, x6};
     float2v av = {a, a}, bv = {b, b};
+    double d0 = x0, d1 = x1, d2 = x2, d3 = x3, d4 = x4, d5 = x5, d6 = x6, d7 = x7, da = a, db = b;
     unsigned s0 = 0, s1 = 1, s2 = 2, s3 = 3, s4 = 4, s5 = 5, s6 = 6, s7 = 7;
     for (int i = 0; i < iters; ++i) {
         if (MODE == 0) { // 8 independent scalar FMAs
@@ -30,6 +31,10 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float a, float b)
             asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n"
                          "v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n v_pk_fma_f32 %0, %0, %1, %2\n"
                          : "+v"(p0) : "v"(av), "v"(bv));
+        } else if (MODE == 7) { // 8 independent double-precision FMAs
+            asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n"
+                         "v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(da), "v"(db));
         } else if (MODE == 5) { // 8 independent scalar-ALU adds
             asm volatile("s_add_u32 %0, %0, %8\n s_add_u32 %1, %1, %8\n s_add_u32 %2, %2, %8\n s_add_u32 %3, %3, %8\n"
                          "s_add_u32 %4, %4, %8\n s_add_u32 %5, %5, %8\n s_add_u32 %6, %6, %8\n s_add_u32 %7, %7, %8\n"
@@ -40,6 +45,7 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float a, float b)
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : "s"(iters), "v"(a), "v"(b) : "scc");
         }
     }
+    x0 += (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
     x0 += (float)(s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7);
     out[blockIdx.x * 64 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y;
 }
@@ -69,6 +75,7 @@ int main() {
         run<2>("v_fma_f32 chain", d, w);
         run<4>("v_pk_fma_f32 chain", d, w);
         run<3>("v_pk_add_f32 indep", d, w);
+        run<7>("v_fma_f64 indep", d, w);
         run<5>("s_add_u32 indep", d, w);
         run<6>("4 v_fma + 4 s_add", d, w);
     }

@@ -256,19 +256,31 @@ __global__ __launch_bounds__(64) void k_hyp(HypArgs a) {
     }
 }
 
-__device__ __forceinline__ double reproj_e2(const double* R, const double* t, double K0, double K1, double K2,
-                                            double K4, double K5, double X0, double X1, double X2, double u, double v) {
-    double xc = ((R[0] * X0 + R[1] * X1) + R[2] * X2) + t[0];
-    double yc = ((R[3] * X0 + R[4] * X1) + R[5] * X2) + t[1];
-    double zc = ((R[6] * X0 + R[7] * X1) + R[8] * X2) + t[2];
-    double up = (K0 * xc + K1 * yc) + K2 * zc;
-    double vp = K4 * yc + K5 * zc;
-    double du = u - up / zc, dv = v - vp / zc;
-    return du * du + dv * dv;
+// Scoring arithmetic (oracle/vo_oracle.h N9).  Each pose is folded once into the 3x4 projection
+// Pm = K [R_cw | t_cw]; the projection is kept homogeneous, so the inlier test needs no division:
+//   ez = (u*z - u~)^2 + (v*z - v~)^2 < thr^2 * z^2,
+// with explicit fused multiply-adds in a fixed order.  Only inliers pay for e2 = ez / z^2 (MSAC term).
+__device__ __forceinline__ double proj_elem(const double* Rt, const double* K, int r, int c) {
+    const double g0 = c < 3 ? Rt[c] : Rt[9], g1 = c < 3 ? Rt[3 + c] : Rt[10], g2 = c < 3 ? Rt[6 + c] : Rt[11];
+    if (r == 0) return fma(K[2], g2, fma(K[1], g1, K[0] * g0));
+    if (r == 1) return fma(K[5], g2, K[4] * g1);
+    return g2;
+}
+struct ProjT { double ez, z2; };
+__device__ __forceinline__ ProjT proj_terms(const double* P, double X0, double X1, double X2, double u, double v) {
+    const double up = fma(P[2], X2, fma(P[1], X1, fma(P[0], X0, P[3])));
+    const double vp = fma(P[6], X2, fma(P[5], X1, fma(P[4], X0, P[7])));
+    const double zc = fma(P[10], X2, fma(P[9], X1, fma(P[8], X0, P[11])));
+    const double du = fma(u, zc, -up), dv = fma(v, zc, -vp);
+    ProjT r;
+    r.ez = fma(dv, dv, du * du);
+    r.z2 = zc * zc;
+    return r;
 }
 
 constexpr int SC_HB = 2;          // hypotheses per block
 constexpr int SC_NS = 4 * SC_HB;  // poses per block
+constexpr int SC_PT = 4;          // points per thread and pass
 
 struct ScoreArgs {
     const double* xy; vo_strides sxy; const double* X; vo_strides sX; int M;
@@ -285,24 +297,51 @@ __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
     if (tid < SC_NS * 12) {
         const int hs = tid / 12;             // pose within the block
         const int h = h0 + hs / 4;
-        sRt[tid] = h < a.H ? a.Rt[48 * (long)h0 + tid] : 0.0;
+        const int e = tid - 12 * hs;         // element of the pose's 3x4 projection
+        sRt[tid] = h < a.H ? proj_elem(a.Rt + 48 * (long)h0 + 12 * hs, a.K, e >> 2, e & 3) : 0.0;
     }
     __syncthreads();
-    const double K0 = a.K[0], K1 = a.K[1], K2 = a.K[2], K4 = a.K[4], K5 = a.K[5];
     const double thr2 = a.thr2;
     const unsigned long long qthr = (unsigned long long)(thr2 * 1048576.0);
     int cnt[SC_NS];
-    unsigned long long cost[SC_NS];
+    unsigned long long cost[SC_NS]; // inlier terms only; the outliers' (M - cnt) * qthr is added at the end
 #pragma unroll
     for (int s = 0; s < SC_NS; ++s) { cnt[s] = 0; cost[s] = 0; }
-    for (int i = tid; i < a.M; i += 256) {
-        const double X0 = a.X[i * a.sX.xi], X1 = a.X[i * a.sX.xi + a.sX.xc], X2 = a.X[i * a.sX.xi + 2 * a.sX.xc];
-        const double u = a.xy[i * a.sxy.xi], v = a.xy[i * a.sxy.xi + a.sxy.xc];
+    // SC_PT points per thread and pass: a pose read from LDS serves all of them
+    for (int i0 = tid; i0 < a.M; i0 += 256 * SC_PT) {
+        double X0[SC_PT], X1[SC_PT], X2[SC_PT], u[SC_PT], v[SC_PT];
+        bool has[SC_PT];
+#pragma unroll
+        for (int p = 0; p < SC_PT; ++p) {
+            const int i = i0 + 256 * p;
+            has[p] = i < a.M;
+            const int j = has[p] ? i : i0;
+            X0[p] = a.X[j * a.sX.xi]; X1[p] = a.X[j * a.sX.xi + a.sX.xc]; X2[p] = a.X[j * a.sX.xi + 2 * a.sX.xc];
+            u[p] = a.xy[j * a.sxy.xi]; v[p] = a.xy[j * a.sxy.xi + a.sxy.xc];
+        }
 #pragma unroll
         for (int s = 0; s < SC_NS; ++s) {
-            const double e2 = reproj_e2(sRt + 12 * s, sRt + 12 * s + 9, K0, K1, K2, K4, K5, X0, X1, X2, u, v);
-            if (e2 < thr2) { ++cnt[s]; cost[s] += (unsigned long long)(e2 * 1048576.0); }
-            else cost[s] += qthr;
+            double P[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) P[k] = sRt[12 * s + k];
+            ProjT t[SC_PT];
+            bool in[SC_PT], any = false;
+#pragma unroll
+            for (int p = 0; p < SC_PT; ++p) {
+                t[p] = proj_terms(P, X0[p], X1[p], X2[p], u[p], v[p]);
+                in[p] = has[p] && (t[p].ez < thr2 * t[p].z2);
+                cnt[s] += (int)in[p];
+                any = any || in[p];
+            }
+            if (any) { // a real branch (the empty asm keeps it from being if-converted): most waves of
+                       // most poses hold no inlier and skip the division
+                asm volatile("" ::: "memory");
+                unsigned long long q = 0;
+#pragma unroll
+                for (int p = 0; p < SC_PT; ++p)
+                    if (in[p]) q += (unsigned long long)((t[p].ez / t[p].z2) * 1048576.0);
+                cost[s] += q;
+            }
         }
     }
     const int lane = tid & 63, wid = tid >> 6;
@@ -317,8 +356,10 @@ __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
     if (tid < SC_NS) {
         const int h = h0 + tid / 4;
         if (h < a.H) {
-            a.cnt[4 * (long)h0 + tid] = (s_cnt[0][tid] + s_cnt[1][tid]) + (s_cnt[2][tid] + s_cnt[3][tid]);
-            a.cost[4 * (long)h0 + tid] = (s_cost[0][tid] + s_cost[1][tid]) + (s_cost[2][tid] + s_cost[3][tid]);
+            const int c = (s_cnt[0][tid] + s_cnt[1][tid]) + (s_cnt[2][tid] + s_cnt[3][tid]);
+            a.cnt[4 * (long)h0 + tid] = c;
+            a.cost[4 * (long)h0 + tid] = (s_cost[0][tid] + s_cost[1][tid]) + (s_cost[2][tid] + s_cost[3][tid]) +
+                                         (unsigned long long)(a.M - c) * qthr;
         }
     }
     if (tid == 0 && a.counters) atomicAdd(&a.counters[4 * (blockIdx.x & (VO_COUNTER_SHARDS - 1)) + 3], (unsigned long long)min(SC_HB, a.H - h0));
@@ -431,13 +472,12 @@ __global__ __launch_bounds__(256) void k_inliers(InlArgs a) {
     int32_t* info = (int32_t*)(a.out + 12);
     bool in = false;
     if (i < a.M && info[0] == 0) {
-        double R[9], t[3];
-        for (int k = 0; k < 9; ++k) R[k] = a.out[k];
-        for (int k = 0; k < 3; ++k) t[k] = a.out[9 + k];
-        const double e2 = reproj_e2(R, t, a.K[0], a.K[1], a.K[2], a.K[4], a.K[5], a.X[i * a.sX.xi],
-                                    a.X[i * a.sX.xi + a.sX.xc], a.X[i * a.sX.xi + 2 * a.sX.xc], a.xy[i * a.sxy.xi],
-                                    a.xy[i * a.sxy.xi + a.sxy.xc]);
-        in = e2 < a.thr2;
+        double P[12];
+        for (int k = 0; k < 12; ++k) P[k] = proj_elem(a.out, a.K, k >> 2, k & 3);
+        const ProjT p = proj_terms(P, a.X[i * a.sX.xi],
+                                   a.X[i * a.sX.xi + a.sX.xc], a.X[i * a.sX.xi + 2 * a.sX.xc], a.xy[i * a.sxy.xi],
+                                   a.xy[i * a.sxy.xi + a.sxy.xc]);
+        in = p.ez < a.thr2 * p.z2;
     }
     if (i < a.M) a.inliers[i] = in ? 1 : 0;
     const unsigned long long bal = __ballot(in);
