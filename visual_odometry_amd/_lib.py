@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvo_hip.so")
+LIB_PATH = os.environ.get("VO_HIP_LIB") or os.path.join(_HERE, "libvo_hip.so")  # VO_HIP_LIB: A/B builds when profiling
 
 VO_OK = 0
 SCORER_MINEIGEN, SCORER_HARRIS = 0, 1

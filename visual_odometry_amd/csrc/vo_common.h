@@ -7,7 +7,7 @@
 #include "../../include/vo_hip.h"
 
 #define VO_MAX_LEVELS 8
-#define VO_MIN_EIG 1e-3f
+#define VO_MIN_EIG 1e-3
 
 #define VO_COUNTER_SHARDS 256 // counters are sharded by keypoint / block index to avoid one hot word
 

@@ -30,7 +30,7 @@ struct LKArgs {
     int nu0, nv0;
     int levels, wu, wv, npx, max_iters, n;
     float eps2;
-    double max_bidir;
+    double max_bidir, flat_thr; // flat_thr = 2 * npx * VO_MIN_EIG
     const double *pu, *pv;
     double *qu, *qv;
     uint8_t* valid;
@@ -157,11 +157,12 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     const int nu0 = a.nu0, nv0 = a.nv0;
     double gu = 0, gv = 0;
     int flags = 0;
+    bool staged0 = false; // level 0: is a B patch staged, and where (re-used by the score)
+    int pou0 = 0, pov0 = 0;
     for (int l = a.levels - 1; l >= 0; --l) {
-        const double s = (double)(1 << l);
         int nu, nv; long lo;
         level_dims(nu0, nv0, l, nu, nv, lo);
-        const double plu = su / s, plv = sv / s;
+        const double plu = ldexp(su, -l), plv = ldexp(sv, -l); // = su / 2^l, exact
         float sxx = 0, sxy = 0, syy = 0, ctu = 0, ctv = 0;
         {   // ---- template set-up: E = samples on the window grown by one pixel, Sobel/8 of E.
             // Rows stream through a 3-row ring so that only 3 x (BW+2) samples are live at a time.
@@ -214,15 +215,17 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
         const double Guu = (double)wave_sum(sxx) * 0.015625, Guv = (double)wave_sum(sxy) * 0.015625, Gvv = (double)wave_sum(syy) * 0.015625;
         const float CTu = wave_sum(ctu), CTv = wave_sum(ctv);
         const double dif = Guu - Gvv;
-        const double mineig = ((Guu + Gvv) - sqrt(dif * dif + 4.0 * (Guv * Guv))) / (2.0 * (double)a.npx);
+        // mineig(G) / npx >= VO_MIN_EIG without the division: 2 * mineig(G) >= 2 * npx * VO_MIN_EIG
+        const double mineig2 = (Guu + Gvv) - sqrt(dif * dif + 4.0 * (Guv * Guv));
         const double det = Guu * Gvv - Guv * Guv;
         float du = 0, dv = 0;
-        const bool flat = !(mineig >= (double)VO_MIN_EIG);
+        const bool flat = !(mineig2 >= a.flat_thr);
         if (flat) {
             if (l == 0) flags |= 2;
         } else {
             // the residual sums carry the x8 of the gradients: 1/8 goes into the inverse
-            const float iuu = unif((float)(Gvv / det) * 0.125f), iuv = unif((float)(-Guv / det) * 0.125f), ivv = unif((float)(Guu / det) * 0.125f);
+            const double idet = 0.125 / det;
+            const float iuu = unif((float)(Gvv * idet)), iuv = unif((float)(-Guv * idet)), ivv = unif((float)(Guu * idet));
             // position = (ibu + fbu + du, ibv + fbv + dv): integer base + float remainder
             const double bu0 = plu + gu, bv0 = plv + gv;
             const double fbu0 = floor(bu0), fbv0 = floor(bv0);
@@ -289,6 +292,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                 du = unif(du + ddu); dv = unif(dv + ddv);
                 if (ddu * ddu + ddv * ddv < a.eps2) break;
             }
+            if (l == 0) { staged0 = staged; pou0 = pou; pov0 = pov; }
         }
         if (flags & 1) break;
         if (l > 0) { gu = 2.0 * (gu + (double)du); gv = 2.0 * (gv + (double)dv); }
@@ -299,13 +303,19 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
         if (!(qu >= 0.0 && qu <= (double)(nu0 - 1) && qv >= 0.0 && qv <= (double)(nv0 - 1))) flags |= 1;
     }
     ssd_out = 0.0f;
-    if (SCORE && !(flags & 1)) { // N5 residual at level 0: re-sample the level-0 template, then the match
-        float T[BH][BW];
+    if (SCORE && !(flags & 1)) { // N5 residual at level 0: the match J first (the level-0 B patch is
+                                 // usually still staged around it), then the re-sampled template
+        float J[BH][BW];
         {
-            const double flu = floor(su), flv = floor(sv);
-            stage<C>(patch, A, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane, lr, lq);
-            const float fu = unif((float)(su - flu)), fv = unif((float)(sv - flv));
-            const int base = lbase + LK_M * PW + LK_M;
+            const double flu = floor(qu), flv = floor(qv);
+            const int iu = uni((int)flu), iv = uni((int)flv);
+            int fi = iu - ru - pou0, fj = iv - rv - pov0;
+            if (!staged0 || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) {
+                stage<C>(patch, B, nu0, nv0, iu - ru - LK_M, iv - rv - LK_M, lane, lr, lq);
+                fi = LK_M; fj = LK_M;
+            }
+            const float fu = unif((float)(qu - flu)), fv = unif((float)(qv - flv));
+            const int base = lbase + fj * PW + fi;
             float hp[BW];
 #pragma unroll
             for (int r = 0; r < BH + 1; ++r) {
@@ -316,15 +326,15 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                 for (int c = 0; c < BW; ++c) p[c] = p[c] + fu * (p[c + 1] - p[c]);
                 if (r > 0) {
 #pragma unroll
-                    for (int c = 0; c < BW; ++c) T[r - 1][c] = hp[c] + fv * (p[c] - hp[c]);
+                    for (int c = 0; c < BW; ++c) J[r - 1][c] = hp[c] + fv * (p[c] - hp[c]);
                 }
 #pragma unroll
                 for (int c = 0; c < BW; ++c) hp[c] = p[c];
             }
         }
-        const double flu = floor(qu), flv = floor(qv);
-        stage<C>(patch, B, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane, lr, lq);
-        const float fu = unif((float)(qu - flu)), fv = unif((float)(qv - flv));
+        const double flu = floor(su), flv = floor(sv);
+        stage<C>(patch, A, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane, lr, lq);
+        const float fu = unif((float)(su - flu)), fv = unif((float)(sv - flv));
         const int base = lbase + LK_M * PW + LK_M;
         float ssd = 0;
         float hp[BW];
@@ -339,7 +349,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
 #pragma unroll
                 for (int c = 0; c < BW; ++c) {
                     const bool in = (mask >> ((r - 1) * BW + c)) & 1ull;
-                    const float e = T[r - 1][c] - (hp[c] + fv * (p[c] - hp[c]));
+                    const float e = (hp[c] + fv * (p[c] - hp[c])) - J[r - 1][c];
                     ssd += in ? e * e : 0.0f;
                 }
             }
@@ -427,6 +437,7 @@ int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d
     a.levels = A->levels; a.wu = wu; a.wv = wv;
     a.npx = wu * wv; a.max_iters = max_iters; a.n = n;
     a.eps2 = (float)(eps * eps); a.max_bidir = max_bidir;
+    a.flat_thr = 2.0 * (double)a.npx * (double)VO_MIN_EIG;
     a.pu = d_pu; a.pv = d_pv; a.qu = d_qu; a.qv = d_qv; a.valid = d_valid; a.score = d_score; a.fb = d_fb;
     a.counters = ctx->d_counters;
     if (wu <= CfgS::MAXU && wv <= CfgS::MAXV) launch<CfgS>(a, ctx->stream);
