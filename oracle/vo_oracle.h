@@ -16,9 +16,10 @@
  * known-answer tests (tests/test_oracle_*.py) and by the fixtures under tests/golden/ that it
  * emitted itself (tests/golden/make_golden.py).
  *
- * All arithmetic is IEEE double, compiled with -ffp-contract=off (no FMA fusion), so that the
- * integer / double decision paths (selection indices, inlier sets) can be reproduced bit-exactly
- * by the HIP side, which uses the same operation order.
+ * All arithmetic is IEEE double, compiled with -ffp-contract=off (the compiler fuses nothing; the
+ * only fused operations are the explicit fma() calls of the N9 scoring), so that the integer /
+ * double decision paths (selection indices, inlier sets) can be reproduced bit-exactly by the HIP
+ * side, which uses the same operation order.
  *
  * ---------------------------------------------------------------------------------------------
  * Internal image convention: an image is `nu` x `nv` uint8, u = FAST (contiguous) axis, v = slow
@@ -58,8 +59,12 @@
  *                single precision (modules/selectCandidateKeypoints.m:23-29, strict <);
  *                selectUniform: rounds of "strongest per grid cell" (ties: lower index) with
  *                h=max(floor(sqrt(n/aspect)),1), w=max(floor(h*aspect),1) until n points.
- * N9 P3P-RANSAC  Philox4x32-10 sample stream; Kneip P3P + Ferrari quartic (complex); scoring in
- *                double with fixed operation order; see p3p.c.
+ * N9 P3P-RANSAC  Philox4x32-10 sample stream; Kneip P3P + Ferrari quartic (complex).  Scoring in
+ *                double: Pm = K [R_cw | t_cw] per pose; (u~, v~, z) = Pm [X; 1] by fma chains;
+ *                inlier iff (u*z - u~)^2 + (v*z - v~)^2 < thr^2 * z^2 (the homogeneous form of
+ *                |p - proj|^2 < thr^2, old/ransacLocalization.m:96-99; z = 0 is never an inlier);
+ *                MSAC cost = sum over inliers of floor(e2 * 2^20), e2 = ez / z^2, plus
+ *                floor(thr^2 * 2^20) per outlier; see p3p.c.
  */
 #ifndef VO_ORACLE_H
 #define VO_ORACLE_H
