@@ -94,6 +94,38 @@ def test_klt_kitti_size_against_oracle_and_truth(ctx):
     assert np.array_equal(qu, qu2) and np.array_equal(qv, qv2) and np.array_equal(valid, valid2)
 
 
+@pytest.mark.parametrize("wu,wv,levels", [(7, 7, 3), (21, 21, 3), (23, 19, 2), (35, 31, 4), (41, 41, 4), (45, 41, 3),
+                                          (41, 45, 3), (51, 51, 4), (55, 55, 2), (3, 55, 2)])
+def test_klt_window_classes_and_borders(ctx, wu, wv, levels):
+    """Every window class of k_lk (CfgS/M/L/X, square and not), with keypoints right up to the image
+    border: both staging forms (16-byte rows with per-lane row clamps, 4-byte rows with column
+    clamps) and the lost / flat exits, against the oracle."""
+    nv, nu = 150, 210
+    img1, img2, _ = synth.frame_pair(nv=nv, nu=nu, seed=11, shift=(1.7, -1.2), zoom=0.003)
+    pu, pv = synth.keypoints(400, nv=nv, nu=nu, seed=12, border=0.0)
+    qu, qv, valid, score = klt_gpu(img1, img2, pu, pv, levels, wu, wv, 30, 1.5)
+    ou, ov, ovalid, oscore, *_ = oracle.klt_track(img1, img2, pu, pv, levels=levels, max_bidir=1.5, wu=wu, wv=wv,
+                                                  max_iters=30, threads=8)
+    assert (valid == ovalid).mean() >= 0.97
+    both = valid & ovalid
+    assert both.sum() > 100
+    assert np.hypot(qu - ou, qv - ov)[both].max() < PX_TOL
+    assert np.abs(score - oscore)[both].max() < 1e-3
+
+
+@pytest.mark.parametrize("nv,nu", [(40, 48), (33, 200), (200, 37), (24, 24)])
+def test_klt_images_smaller_than_the_patch(ctx, nv, nu):
+    """Images narrower / lower than the staged patch: every level is replicate-clamped."""
+    img1, img2, _ = synth.frame_pair(nv=nv, nu=nu, seed=13, shift=(0.8, 0.6), margin=16)
+    pu, pv = synth.keypoints(64, nv=nv, nu=nu, seed=14, border=2.0)
+    qu, qv, valid, score = klt_gpu(img1, img2, pu, pv, 3, 31, 31, 30, 2.0)
+    ou, ov, ovalid, oscore, *_ = oracle.klt_track(img1, img2, pu, pv, levels=3, max_bidir=2.0, wu=31, wv=31, max_iters=30)
+    assert (valid == ovalid).mean() >= 0.95
+    both = valid & ovalid
+    if both.any():
+        assert np.hypot(qu - ou, qv - ov)[both].max() < PX_TOL
+
+
 # ---------------------------------------------------------------- selection
 def sel_gpu(img, eu, ev, col_major, **kw):
     """internal-coordinate call in either layout; returns u, v, lin, metric like the oracle."""
