@@ -199,6 +199,52 @@ int vo_dev_p3p_ransac(vo_ctx* ctx, const double* d_xy, const double* d_X, int M,
                       const vo_ransac_opts* opts, const int32_t* d_sample_idx,
                       const double* d_hyp_poses_in, void* d_out, uint8_t* d_inliers);
 
+/* ==== device-resident frame loop: VisualOdometry.processFrame,
+ * modules/VisualOdometry.m:264-346, with the method candidateTriangulation (:63-151), the state kept
+ * in HBM across the five steps and across frames.  Replaces the MATLAB state struct
+ * {landmarks, keypoints, reproError, candidate_keypoints, candidate_first_keypoints,
+ * candidate_first_poses, candidate_time_indxs} (:308-315, :338-345).  Conventions: row-major host
+ * arrays, (u,v) zero-based with K in the same origin, poses 4x3 row-major [R_WC; t_WC] (:318).
+ * Not thread-safe per state; everything runs on the ctx stream. ==== */
+typedef struct vo_frame_state vo_frame_state;
+typedef struct vo_frame_opts {
+    int max_landmarks;            /* maxNumLandmarks, :24 */
+    int max_candidates;           /* capacity of the candidate arrays (a cell array in the reference) */
+    int max_temporal_recall;      /* maxTemporalRecall, :23 */
+    double angular_threshold_deg; /* angularThreshold, :22 */
+    double max_reproj_err;        /* maxReprojectionError, :25; strict < at :302, <= at :106 */
+    vo_klt_opts klt;              /* :33-37 */
+    vo_ransac_opts pose;          /* :285-289; seed + frame number seeds each frame's sample stream */
+    vo_sel_opts sel;              /* :332-335 */
+} vo_frame_opts;
+typedef struct vo_frame_info {
+    int32_t status;        /* pose status 0 / 1 / 2 as vo_ransac_info */
+    int32_t n_landmarks, n_candidates;   /* sizes of the new state */
+    int32_t n_tracked;     /* landmarks' keypoints that tracked validly (:280) */
+    int32_t n_inliers, trials_used;
+    int32_t n_promoted;    /* candidates appended as landmarks (:123-127) */
+    int32_t n_new;         /* new candidate keypoints (:330-345) */
+    int32_t overflow;      /* 1 when new candidates were cut at max_candidates */
+    int32_t frame_no;
+} vo_frame_info;
+int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* opts, int nu, int nv, const double K[9], vo_frame_state** out);
+int vo_frame_destroy(vo_ctx* ctx, vo_frame_state* st);
+/* load a state (e.g. from bootstrap): landmarks N x 3, keypoints N x 2, repro N, candidates C x 2 twice,
+ * first poses C x 12, time indices C (<= -1); frame_no = frames processed so far */
+int vo_frame_set_state(vo_ctx* ctx, vo_frame_state* st, const double* landmarks, const double* keypoints,
+                       const double* repro_err, int N, const double* cand_keypoints, const double* cand_first_keypoints,
+                       const double* cand_first_poses, const int32_t* cand_time_idx, int C, int frame_no);
+int vo_frame_get_counts(vo_ctx* ctx, vo_frame_state* st, int* N, int* C);
+/* outputs sized by vo_frame_get_counts; any pointer may be NULL */
+int vo_frame_get_state(vo_ctx* ctx, vo_frame_state* st, double* landmarks, double* keypoints, double* repro_err,
+                       double* cand_keypoints, double* cand_first_keypoints, double* cand_first_poses,
+                       int32_t* cand_time_idx);
+/* the previous image of the next vo_frame_process call (nv rows of nu bytes; on_device: a device pointer) */
+int vo_frame_set_image(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device);
+/* one processFrame: prev image = the last image given; returns the pose [R_WC; t_WC] and the counts */
+int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device, double pose43[12],
+                     vo_frame_info* info);
+
 #ifdef __cplusplus
 }
 #endif

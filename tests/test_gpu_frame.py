@@ -1,0 +1,141 @@
+"""The device-resident frame loop (vo_frame_*) against the oracle's restatement of
+VisualOdometry.processFrame (oracle/vo_frame.py), through the C ABI.  Bars as in test_gpu_parity:
+tracked positions 0.01 px, landmarks / poses 1e-4 relative; counts and time indices exact."""
+import numpy as np
+import pytest
+
+from oracle import oracle, vo_frame
+from visual_odometry_amd import _lib, synth
+from visual_odometry_amd.frame import FrameLoop
+
+pytestmark = pytest.mark.gpu
+K = np.array([[300.0, 0, 160.0], [0, 300.0, 120.0], [0, 0, 1.0]])
+PX_TOL = 0.01
+
+
+def start_state(img, lift, n=150):
+    u, v, _, _ = oracle.select_candidates(img, np.zeros(0, np.float32), np.zeros(0, np.float32), min_distance=7, keep=n)
+    st = vo_frame.new_state()
+    st.keypoints = np.stack([u, v], 1).astype(np.float64)
+    st.landmarks = lift(st.keypoints[:, 0], st.keypoints[:, 1])
+    st.reproError = np.zeros(len(u))
+    return st
+
+
+def assert_states_match(g, o):
+    assert len(g.landmarks) == len(o.landmarks) and len(g.candidate_keypoints) == len(o.candidate_keypoints)
+    if len(o.landmarks):
+        assert np.abs(g.keypoints - o.keypoints).max() < PX_TOL
+        np.testing.assert_allclose(g.landmarks, o.landmarks, rtol=1e-4, atol=1e-4)
+        assert np.abs(g.reproError - o.reproError).max() < PX_TOL
+    if len(o.candidate_keypoints):
+        assert np.abs(g.candidate_keypoints - o.candidate_keypoints).max() < PX_TOL
+        np.testing.assert_array_equal(g.candidate_first_keypoints, o.candidate_first_keypoints)
+        np.testing.assert_allclose(g.candidate_first_poses, o.candidate_first_poses, rtol=1e-4, atol=1e-5)
+        np.testing.assert_array_equal(g.candidate_time_indxs, o.candidate_time_indxs)
+
+
+@pytest.fixture(scope="module")
+def sequence():
+    return synth.plane_sequence(14, K)
+
+
+def test_each_frame_matches_the_oracle_from_the_same_state(ctx, sequence):
+    """Same input state on both sides for every frame; the landmark cap (120) is reached, so the
+    replace-the-worst policy (:116-122), promotion (:123-127) and ageing (:130-139) all run."""
+    frames, poses, lift = sequence
+    st = start_state(frames[0], lift)
+    loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=160, ctx=ctx)
+    seen = dict(promoted=0, replaced=0, aged_out=0)
+    for k in range(1, len(frames)):
+        loop.set_state(st, frames[k - 1], frame_no=k - 1)
+        gpose, gstatus, ginfo = loop.processFrame(frames[k])
+        st2, pose, status, info = vo_frame.process_frame(frames[k - 1], frames[k], st, K, k, maxNumLandmarks=160)
+        assert gstatus == status == 0
+        np.testing.assert_allclose(gpose, pose, rtol=1e-4, atol=1e-5)
+        assert (ginfo["n_tracked"], ginfo["n_promoted"], ginfo["n_new"]) == (info["tracked"], info["promoted"], info["new"])
+        assert_states_match(loop.get_state(), st2)
+        seen["promoted"] += info["promoted"]; seen["replaced"] += info["replaced"]
+        st = st2
+    assert seen["promoted"] > 0 and seen["replaced"] > 0
+    assert st.candidate_time_indxs.min() < -1          # candidates were carried and aged
+    loop.close()
+
+
+def test_a_chain_of_frames_stays_on_the_oracle_chain(ctx, sequence):
+    """No re-upload: the state stays in HBM for the whole sequence."""
+    frames, poses, lift = sequence
+    st = start_state(frames[0], lift)
+    loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=200, ctx=ctx)
+    loop.set_state(st, frames[0])
+    for k in range(1, len(frames)):
+        gpose, gstatus, ginfo = loop.processFrame(frames[k])
+        st, pose, status, info = vo_frame.process_frame(frames[k - 1], frames[k], st, K, k, maxNumLandmarks=200)
+        assert gstatus == status
+        assert abs(ginfo["n_landmarks"] - len(st.landmarks)) <= 2 and abs(ginfo["n_candidates"] - len(st.candidate_keypoints)) <= 2
+        assert np.abs(gpose - pose).max() < 1e-3
+    g = loop.get_state()
+    assert loop.counts() == (len(g.landmarks), len(g.candidate_keypoints))
+    # the estimated trajectory follows the true one (minimal-sample poses on a plane: loose bound)
+    assert np.abs(gpose[3] - poses[-1][3]).max() < 0.5
+    loop.close()
+
+
+def test_empty_and_tiny_states(ctx, sequence):
+    """Fewer than 4 tracked landmarks: status 1 and the identity pose (toolbox semantics), the
+    selection step still seeds candidates."""
+    frames, _, lift = sequence
+    loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=50, CandidatesToKeep=40, ctx=ctx)
+    loop.set_state(vo_frame.new_state(), frames[0])
+    pose, status, info = loop.processFrame(frames[1])
+    o, opose, ostatus, oinfo = vo_frame.process_frame(frames[0], frames[1], vo_frame.new_state(), K, 1, maxNumLandmarks=50, keep=40)
+    assert status == ostatus == 1 and info["n_landmarks"] == 0 and info["n_new"] == oinfo["new"] == 40
+    np.testing.assert_array_equal(pose, np.vstack([np.eye(3), np.zeros((1, 3))]))
+    assert_states_match(loop.get_state(), o)
+    st = start_state(frames[0], lift, n=3)
+    loop.set_state(st, frames[0])
+    pose, status, info = loop.processFrame(frames[1])
+    assert status == 1 and info["n_tracked"] <= 3
+    loop.close()
+
+
+def test_candidate_capacity_overflow_is_flagged(ctx, sequence):
+    frames, _, lift = sequence
+    loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=200, maxCandidates=130, ctx=ctx)
+    loop.set_state(start_state(frames[0], lift), frames[0])
+    _, _, i1 = loop.processFrame(frames[1])
+    _, _, i2 = loop.processFrame(frames[2])
+    assert i1["overflow"] == 0 and i1["n_candidates"] == 100
+    assert i2["overflow"] == 1 and i2["n_candidates"] == 130
+    loop.close()
+
+
+def test_bad_calls_raise(ctx, sequence):
+    frames, _, lift = sequence
+    loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=20, ctx=ctx)
+    with pytest.raises(_lib.VoError):
+        loop.processFrame(frames[1])                       # no previous image yet
+    with pytest.raises(_lib.VoError):
+        loop.set_state(start_state(frames[0], lift, n=60))  # more landmarks than max_landmarks
+    with pytest.raises(ValueError):
+        loop.set_image(frames[0][:100])
+    with pytest.raises(_lib.VoError):
+        FrameLoop(K, frames[0].shape, maxNumLandmarks=2, ctx=ctx)
+    loop.close()
+
+
+def test_device_images_and_kitti_shape(ctx):
+    """Device-resident uint8 frames at 1241 x 376 with the reference's defaults (300 landmarks)."""
+    import torch
+    Kk = synth.KITTI_K
+    frames, poses, lift = synth.plane_sequence(4, Kk, nv=376, nu=1241, depth=20.0, step=(0.2, 0.0, 0.15))
+    st = start_state(frames[0], lift, n=300)
+    dev = [torch.from_numpy(f).to("cuda") for f in frames]
+    loop = FrameLoop(Kk, frames[0].shape, ctx=ctx)
+    loop.set_state(st, dev[0])
+    for k in range(1, 4):
+        gpose, gstatus, ginfo = loop.processFrame(dev[k])
+        st, pose, status, info = vo_frame.process_frame(frames[k - 1], frames[k], st, Kk, k)
+        assert gstatus == status == 0 and np.abs(gpose - pose).max() < 1e-3
+        assert abs(ginfo["n_landmarks"] - len(st.landmarks)) <= 2
+    loop.close()

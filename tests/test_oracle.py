@@ -287,3 +287,23 @@ def test_ransac_statuses_and_adaptive_stop():
     same = oracle.p3p_ransac(xy, X, K, num_hyp=500, seed=77)
     tab = oracle.p3p_ransac(xy, X, K, num_hyp=500, seed=1, sample_idx=table)
     assert same["best_hyp"] == tab["best_hyp"] and (same["inliers"] == tab["inliers"]).all()
+
+
+def test_frame_step_restatement_runs_a_sequence():
+    """oracle/vo_frame.py (modules/VisualOdometry.m:264-346): landmarks are promoted, the cap holds,
+    candidates age, and the pose follows the camera on a 3D-consistent synthetic sequence."""
+    from oracle import vo_frame
+    K = np.array([[300.0, 0, 160.0], [0, 300.0, 120.0], [0, 0, 1.0]])
+    frames, poses, lift = synth.plane_sequence(6, K)
+    u, v, _, _ = oracle.select_candidates(frames[0], np.zeros(0, np.float32), np.zeros(0, np.float32), min_distance=7, keep=120)
+    st = vo_frame.new_state()
+    st.keypoints = np.stack([u, v], 1).astype(np.float64)
+    st.landmarks = lift(st.keypoints[:, 0], st.keypoints[:, 1]); st.reproError = np.zeros(len(u))
+    promoted = 0
+    for k in range(1, 6):
+        st, pose, status, info = vo_frame.process_frame(frames[k - 1], frames[k], st, K, k, maxNumLandmarks=150, threads=8)
+        assert status == 0 and len(st.landmarks) <= 150
+        assert len(st.candidate_keypoints) == len(st.candidate_first_poses) == len(st.candidate_time_indxs)
+        assert np.abs(pose[3] - poses[k][3]).max() < 0.3 and np.abs(pose[:3] - poses[k][:3]).max() < 0.05
+        promoted += info["promoted"]
+    assert promoted > 0 and st.candidate_time_indxs.min() < -1 and (st.reproError < 3.0).all()

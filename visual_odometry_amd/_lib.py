@@ -44,6 +44,17 @@ class RansacInfo(C.Structure):
                 ("num_inliers", C.c_int)]
 
 
+class FrameOpts(C.Structure):
+    _fields_ = [("max_landmarks", C.c_int), ("max_candidates", C.c_int), ("max_temporal_recall", C.c_int),
+                ("angular_threshold_deg", C.c_double), ("max_reproj_err", C.c_double), ("klt", KltOpts),
+                ("pose", RansacOpts), ("sel", SelOpts)]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("status", "n_landmarks", "n_candidates", "n_tracked", "n_inliers",
+                                         "trials_used", "n_promoted", "n_new", "overflow", "frame_no")]
+
+
 # every symbol include/vo_hip.h declares (tests check that the library exports all of them)
 EXPORTS = [
     "vo_strerror", "vo_version", "vo_ctx_create", "vo_ctx_destroy", "vo_ctx_set_stream", "vo_ctx_get_stream",
@@ -51,7 +62,8 @@ EXPORTS = [
     "vo_klt_track", "vo_select_candidates", "vo_harris_response", "vo_corner_response",
     "vo_select_keypoints_greedy", "vo_triangulate_candidates", "vo_angle_deg", "vo_in_front", "vo_reproj_error",
     "vo_p3p_ransac", "vo_p3p_batch", "vo_dev_frame_build", "vo_dev_klt_track", "vo_dev_select_candidates",
-    "vo_dev_triangulate", "vo_dev_p3p_ransac",
+    "vo_dev_triangulate", "vo_dev_p3p_ransac", "vo_frame_create", "vo_frame_destroy", "vo_frame_set_state",
+    "vo_frame_get_counts", "vo_frame_get_state", "vo_frame_set_image", "vo_frame_process",
 ]
 
 _lib = None
@@ -64,6 +76,15 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise VoError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")
+        # PyTorch-ROCm wheels bundle their own libamdhip64; if this library pulled in /opt/rocm's copy
+        # first, a later `import torch` would bring a second HIP runtime into the process and see no
+        # GPU.  Loading torch first makes both bind to one runtime (torch is only plumbing here).
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = C.CDLL(LIB_PATH)
         lib.vo_strerror.restype = C.c_char_p
         lib.vo_ctx_last_error.restype = C.c_char_p

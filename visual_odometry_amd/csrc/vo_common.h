@@ -94,3 +94,8 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
                      const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
                      const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers);
 int vo_launch_p3p_batch(vo_ctx* ctx, const double* d_P, const double* d_f, int n, double* d_poses);
+
+// ---- helpers of vo_api.hip shared with vo_frame.hip ----
+int vo_int_frame_prepare(vo_ctx* ctx, vo_pyr* f, int nu, int nv, int levels);
+int vo_int_sel_work_prepare(vo_ctx* ctx, int nu, int nv, int keep, int n_exist, double min_distance, vo_sel_work* w);
+int vo_int_ransac_work_prepare(vo_ctx* ctx, int H, vo_ransac_work* w);

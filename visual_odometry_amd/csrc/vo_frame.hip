@@ -1,0 +1,539 @@
+// vo_frame.hip -- device-resident frame loop: VisualOdometry.processFrame
+// (modules/VisualOdometry.m:264-346) with the method candidateTriangulation (:63-151).
+// The MATLAB state struct lives in HBM as structure-of-arrays; the five steps of a frame run on the
+// ctx stream through the same launchers as the stand-alone entry points (vo_launch_klt, _ransac,
+// _reproj, _triangulate, _select), glued by the small ordered-compaction / merge kernels below.
+// Per frame the host reads back three small records (the tracked count, the new landmark /
+// kept-candidate counts, the final counts + pose); no point data crosses PCIe.
+// Normative restatement: oracle/vo_frame.py.
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "vo_common.h"
+
+namespace {
+
+// ---- ordered compaction: pos[i] = number of set flags before i; *count = total.  One block. ----
+__global__ __launch_bounds__(1024) void k_scan_flags(const uint8_t* __restrict__ flag, int n, const int* d_n,
+                                                     int32_t* __restrict__ pos, int32_t* count) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (d_n) n = min(n, *d_n);
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + tid;
+        const int f = (i < n && flag[i]) ? 1 : 0;
+        const unsigned long long bal = __ballot(f);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wid] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wid) woff += wsum[w]; tot += wsum[w]; }
+        const int base = base_s;
+        if (i < n) pos[i] = base + woff + before;
+        __syncthreads();
+        if (tid == 0) base_s = base + tot;
+        __syncthreads();
+    }
+    if (tid == 0) *count = base_s;
+}
+
+// landmarks whose keypoint tracked validly (:280-281): (q, L) -> (vk, vl), pitch = capL
+__global__ void k_gather_tracked(int n, const uint8_t* valid, const int32_t* pos, const double* qu, const double* qv,
+                                 const double* L, int capL, double* vk, double* vl) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !valid[i]) return;
+    const int d = pos[i];
+    vk[d] = qu[i]; vk[capL + d] = qv[i];
+    vl[d] = L[i]; vl[capL + d] = L[capL + i]; vl[2 * capL + d] = L[2 * capL + i];
+}
+
+// :302 strict <
+__global__ void k_flag_less(const double* err, int n, double thr, uint8_t* flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = err[i] < thr ? 1 : 0;
+}
+
+// :308-315 into the merge work arrays (pitch PW), alive = 1
+__global__ void k_gather_kept(int n, const uint8_t* flag, const int32_t* pos, const double* vk, const double* vl,
+                              const double* err, int capL, int PW, double* wkp, double* wL, double* wrep, uint8_t* alive) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const int d = pos[i];
+    wkp[d] = vk[i]; wkp[PW + d] = vk[capL + i];
+    wL[d] = vl[i]; wL[PW + d] = vl[capL + i]; wL[2 * PW + d] = vl[2 * capL + i];
+    wrep[d] = err[i];
+    alive[d] = 1;
+}
+
+// pose [R_WC; t_WC] (:318) from the RANSAC record R_cw, t_cw: C = -R_cw^T t_cw
+__global__ void k_pose_from_rt(const double* out, double* pose) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < 9; ++k) pose[k] = out[k];
+    for (int c = 0; c < 3; ++c) pose[9 + c] = -((out[c] * out[9] + out[3 + c] * out[10]) + out[6 + c] * out[11]);
+}
+__global__ void k_identity_record(double* out, int status) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < 9; ++k) out[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    out[9] = out[10] = out[11] = 0.0;
+    int32_t* info = (int32_t*)(out + 12);
+    info[0] = status; info[1] = -1; info[2] = -1; info[3] = 0; info[4] = 0;
+}
+
+// :106-113, :130: 0 drop, 1 promote (angle large), 2 keep as candidate (angle small, young enough)
+__global__ void k_classify(int n, const uint8_t* tracked, const uint8_t* ok, const double* rep, const double* ang,
+                           const int32_t* ctime, double max_rep, double ang_thr, int recall, uint8_t* cls, uint8_t* keepf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = 0;
+    if (tracked[i] && ok[i] && rep[i] <= max_rep) {
+        if (ang[i] > ang_thr) c = 1;
+        else if (ctime[i] > -recall) c = 2;
+    }
+    cls[i] = (uint8_t)c;
+    keepf[i] = c == 2;
+}
+
+// The order-dependent merge of :87-142 over the promotable candidates, in candidate order.
+// One block.  Landmarks are never moved: a replaced landmark (:116-122) is tombstoned, an
+// accepted one appended (:123-127); the ordered compaction afterwards gives the MATLAB order.
+struct MergeArgs {
+    int nC, cap, PW, capC;
+    const uint8_t* cls;
+    const double *X, *crep, *cq;    // candidates: pitch capC
+    double *wkp, *wL, *wrep; uint8_t* alive;
+    const int32_t* n0;              // landmarks that survived the reprojection filter
+    int32_t* plist;                 // scratch, nC
+    int32_t* n_promoted;
+};
+__global__ __launch_bounds__(1024) void k_merge(MergeArgs a) {
+    __shared__ int wsum[16];
+    __shared__ int s_np, s_alive, s_tot, s_prom;
+    __shared__ double r_val[16];
+    __shared__ int r_idx[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) { s_np = 0; s_alive = *a.n0; s_tot = *a.n0; s_prom = 0; }
+    __syncthreads();
+    // ordered list of the promotable candidates
+    for (int i0 = 0; i0 < a.nC; i0 += 1024) {
+        const int i = i0 + tid;
+        const int f = (i < a.nC && a.cls[i] == 1) ? 1 : 0;
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0) wsum[wid] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wid) woff += wsum[w]; tot += wsum[w]; }
+        const int base = s_np;
+        if (f) a.plist[base + woff + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) s_np = base + tot;
+        __syncthreads();
+    }
+    const int np = s_np;
+    for (int j = 0; j < np; ++j) {
+        const int i = a.plist[j];
+        const double r = a.crep[i];
+        const int alive_now = s_alive, tot = s_tot; // every thread reads before anyone edits
+        __syncthreads();
+        if (alive_now >= a.cap) {
+            // :89-90 first maximum of reproError over the live landmarks
+            double bv = 0; int bi = -1;
+            for (int k = tid; k < tot; k += 1024)
+                if (a.alive[k]) { const double v = a.wrep[k]; if (bi < 0 || v > bv) { bv = v; bi = k; } }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const double ov = __shfl_xor(bv, d, 64); const int oi = __shfl_xor(bi, d, 64);
+                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) { r_val[wid] = bv; r_idx[wid] = bi; }
+            __syncthreads();
+            if (tid == 0) {
+                double mv = 0; int mi = -1;
+                for (int w = 0; w < 16; ++w)
+                    if (r_idx[w] >= 0 && (mi < 0 || r_val[w] > mv || (r_val[w] == mv && r_idx[w] < mi))) { mv = r_val[w]; mi = r_idx[w]; }
+                if (mi >= 0 && r <= mv) { a.alive[mi] = 0; s_alive = s_alive - 1; }   // :116-122
+            }
+        }
+        if (tid == 0 && s_alive < a.cap) {                                             // :123-127
+            const int d = s_tot;
+            a.wL[d] = a.X[i]; a.wL[a.PW + d] = a.X[a.capC + i]; a.wL[2 * a.PW + d] = a.X[2 * a.capC + i];
+            a.wkp[d] = a.cq[i]; a.wkp[a.PW + d] = a.cq[a.capC + i];
+            a.wrep[d] = r;
+            a.alive[d] = 1;
+            s_tot = d + 1; s_alive = s_alive + 1; s_prom = s_prom + 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *a.n_promoted = s_prom;
+}
+
+// ordered compaction of the live landmarks into the next state (pitch capL)
+__global__ void k_gather_landmarks(int n, const uint8_t* alive, const int32_t* pos, int PW, int capL, const double* wkp,
+                                   const double* wL, const double* wrep, double* kp, double* L, double* rep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !alive[i]) return;
+    const int d = pos[i];
+    if (d >= capL) return;
+    kp[d] = wkp[i]; kp[capL + d] = wkp[PW + i];
+    L[d] = wL[i]; L[capL + d] = wL[PW + i]; L[2 * capL + d] = wL[2 * PW + i];
+    rep[d] = wrep[i];
+}
+
+// :130-139 kept candidates, aged by one frame
+__global__ void k_gather_candidates(int n, const uint8_t* keepf, const int32_t* pos, int capC, const double* cq,
+                                    const double* cf, const int32_t* cpose, const int32_t* ctime, double* ncu, double* ncf,
+                                    int32_t* ncpose, int32_t* nctime) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keepf[i]) return;
+    const int d = pos[i];
+    ncu[d] = cq[i]; ncu[capC + d] = cq[capC + i];
+    ncf[d] = cf[i]; ncf[capC + d] = cf[capC + i];
+    ncpose[d] = cpose[i]; nctime[d] = ctime[i] - 1;
+}
+
+// :330-331 [keypoints; candidate_keypoints] cast to single
+__global__ void k_existing(const int32_t* counts, int capL, int capC, const double* kp, const double* cu, float* eu, float* ev) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nL = counts[0], nC = counts[1];
+    if (t < capL) {
+        if (t < nL) { eu[t] = (float)kp[t]; ev[t] = (float)kp[capL + t]; }
+    } else {
+        const int c = t - capL;
+        if (c < nC) { eu[nL + c] = (float)cu[c]; ev[nL + c] = (float)cu[capC + c]; }
+    }
+}
+
+// :338-345 append the new candidates: first keypoint = keypoint, first pose = this frame's, time -1
+__global__ void k_append_new(int32_t* counts, int capC, const float* su, const float* sv, int pose_slot, double* cu,
+                             double* cf, int32_t* cpose, int32_t* ctime) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nC = counts[1];
+    int m = counts[2];
+    const int room = capC - nC;
+    const int take = m < room ? m : room;
+    if (i < take) {
+        const int d = nC + i;
+        const double u = (double)su[i], v = (double)sv[i];
+        cu[d] = u; cu[capC + d] = v; cf[d] = u; cf[capC + d] = v;
+        cpose[d] = pose_slot; ctime[d] = -1;
+    }
+    if (i == 0) { counts[3] = nC + take; counts[4] = m > room ? 1 : 0; counts[5] = take; }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+struct vo_frame_state {
+    vo_frame_opts o;
+    int nu, nv, capL, capC, PW, ring, P;   // P = ring + upload pose slots
+    vo_pyr pyr[2];
+    uint8_t* img[2];
+    int cur;                                // slot holding the previous image
+    bool have_prev;
+    int nL, nC, frame_no;
+    char* arena;
+    // state (S) and next state (N): landmarks 3 x capL, keypoints 2 x capL, repro capL; candidates
+    double *L[2], *kp[2], *rep[2], *cu[2], *cf[2];
+    int32_t *cpose[2], *ctime[2];
+    int s;                                  // index of the current state
+    double *poses, *K, *rsout;
+    // work
+    double *q, *vk, *vl, *err, *cq, *X, *crep, *cang, *wkp, *wL, *wrep;
+    float *score, *eu, *ev, *su, *sv;
+    uint8_t *valid, *flag, *cvalid, *cok, *cls, *keepf, *alive, *inl;
+    int32_t *pos, *plist, *counts, *slin;
+    int32_t* h_counts;                      // pinned
+    double* h_rec;                          // pinned: ransac record (16) + pose (12)
+};
+
+#define ST_CHECK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e__); return e__ == hipErrorOutOfMemory ? VO_ERR_OOM : VO_ERR_HIP; } } while (0)
+
+namespace {
+struct Bump {
+    char* base; size_t off = 0;
+    template <typename T> T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+void carve(vo_frame_state* st, char* base, size_t* total) {
+    Bump b; b.base = base;
+    const size_t cl = st->capL, cc = st->capC, pw = st->PW, mx = std::max(cl, cc);
+    for (int k = 0; k < 2; ++k) {
+        st->L[k] = b.take<double>(3 * cl); st->kp[k] = b.take<double>(2 * cl); st->rep[k] = b.take<double>(cl);
+        st->cu[k] = b.take<double>(2 * cc); st->cf[k] = b.take<double>(2 * cc);
+        st->cpose[k] = b.take<int32_t>(cc); st->ctime[k] = b.take<int32_t>(cc);
+    }
+    st->poses = b.take<double>(12 * (size_t)st->P); st->K = b.take<double>(9); st->rsout = b.take<double>(16);
+    st->q = b.take<double>(2 * cl); st->vk = b.take<double>(2 * cl); st->vl = b.take<double>(3 * cl); st->err = b.take<double>(cl);
+    st->cq = b.take<double>(2 * cc); st->X = b.take<double>(3 * cc); st->crep = b.take<double>(cc); st->cang = b.take<double>(cc);
+    st->wkp = b.take<double>(2 * pw); st->wL = b.take<double>(3 * pw); st->wrep = b.take<double>(pw);
+    st->score = b.take<float>(mx); st->eu = b.take<float>(pw); st->ev = b.take<float>(pw);
+    const size_t keep = (size_t)std::max(st->o.sel.keep, 1);
+    st->su = b.take<float>(keep); st->sv = b.take<float>(keep); st->slin = b.take<int32_t>(keep);
+    st->valid = b.take<uint8_t>(cl); st->flag = b.take<uint8_t>(cl); st->cvalid = b.take<uint8_t>(cc); st->cok = b.take<uint8_t>(cc);
+    st->cls = b.take<uint8_t>(cc); st->keepf = b.take<uint8_t>(cc); st->alive = b.take<uint8_t>(pw); st->inl = b.take<uint8_t>(cl);
+    st->pos = b.take<int32_t>(pw); st->plist = b.take<int32_t>(cc); st->counts = b.take<int32_t>(16);
+    *total = b.off + 256;
+}
+int upload_image(vo_ctx* ctx, vo_frame_state* st, int slot, const uint8_t* img, int on_device) {
+    const size_t nb = (size_t)st->nu * st->nv;
+    ST_CHECK(hipMemcpyAsync(st->img[slot], img, nb, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    int rc = vo_int_frame_prepare(ctx, &st->pyr[slot], st->nu, st->nv, st->o.klt.levels);
+    if (rc) return rc;
+    return vo_launch_frame_build(ctx, &st->pyr[slot], st->img[slot]);
+}
+inline int blocks(int n, int b = 256) { return (n + b - 1) / b; }
+} // namespace
+
+extern "C" {
+
+int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const double K[9], vo_frame_state** out) {
+    if (!ctx || !o || !K || !out) return VO_ERR_BAD_ARG;
+    *out = nullptr;
+    if (o->max_landmarks < 4 || o->max_candidates < 1 || o->max_temporal_recall < 1 || !(o->max_reproj_err > 0) ||
+        o->sel.keep < 0 || o->pose.num_hyp < 1 || nu < 8 || nv < 8) { ctx->last_error = "frame: bad options"; return VO_ERR_BAD_ARG; }
+    (void)hipSetDevice(ctx->device);
+    vo_frame_state* st = new vo_frame_state();
+    st->o = *o; st->nu = nu; st->nv = nv;
+    st->capL = o->max_landmarks; st->capC = o->max_candidates; st->PW = st->capL + st->capC;
+    st->ring = o->max_temporal_recall + 2; st->P = st->ring + o->max_temporal_recall + 64;
+    st->cur = 0; st->have_prev = false; st->nL = st->nC = 0; st->frame_no = 0; st->s = 0;
+    st->arena = nullptr; st->img[0] = st->img[1] = nullptr; st->h_counts = nullptr; st->h_rec = nullptr;
+    size_t total = 0;
+    carve(st, nullptr, &total);
+    hipError_t e = hipMalloc((void**)&st->arena, total);
+    if (e == hipSuccess) e = hipMemsetAsync(st->arena, 0, total, ctx->stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&st->img[0], (size_t)nu * nv);
+    if (e == hipSuccess) e = hipMalloc((void**)&st->img[1], (size_t)nu * nv);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_counts, 16 * sizeof(int32_t), 0);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_rec, 32 * sizeof(double), 0);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("frame: allocation failed: ") + hipGetErrorString(e);
+        vo_frame_destroy(ctx, st);
+        return e == hipErrorOutOfMemory ? VO_ERR_OOM : VO_ERR_HIP;
+    }
+    carve(st, st->arena, &total);
+    ST_CHECK(hipMemcpyAsync(st->K, K, 72, hipMemcpyHostToDevice, ctx->stream));
+    ST_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = st;
+    return VO_OK;
+}
+
+int vo_frame_destroy(vo_ctx* ctx, vo_frame_state* st) {
+    if (!ctx || !st) return VO_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (st->arena) (void)hipFree(st->arena);
+    for (int k = 0; k < 2; ++k) {
+        if (st->img[k]) (void)hipFree(st->img[k]);
+        if (st->pyr[k].I) (void)hipFree(st->pyr[k].I);
+    }
+    if (st->h_counts) (void)hipHostFree(st->h_counts);
+    if (st->h_rec) (void)hipHostFree(st->h_rec);
+    delete st;
+    return VO_OK;
+}
+
+int vo_frame_set_state(vo_ctx* ctx, vo_frame_state* st, const double* landmarks, const double* keypoints,
+                       const double* repro, int N, const double* ck, const double* cfk, const double* cposes,
+                       const int32_t* ctime, int C, int frame_no) {
+    if (!ctx || !st || N < 0 || C < 0 || frame_no < 0) return VO_ERR_BAD_ARG;
+    if (N > st->capL || C > st->capC) { ctx->last_error = "frame: state larger than max_landmarks / max_candidates"; return VO_ERR_BAD_ARG; }
+    if ((N > 0 && (!landmarks || !keypoints || !repro)) || (C > 0 && (!ck || !cfk || !cposes || !ctime))) return VO_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    const int s = st->s, cl = st->capL, cc = st->capC;
+    std::vector<double> hL(3 * (size_t)std::max(N, 1)), hk(2 * (size_t)std::max(N, 1)), hc(2 * (size_t)std::max(C, 1)), hf(2 * (size_t)std::max(C, 1));
+    for (int i = 0; i < N; ++i) {
+        for (int c = 0; c < 3; ++c) hL[(size_t)c * N + i] = landmarks[3 * (size_t)i + c];
+        for (int c = 0; c < 2; ++c) hk[(size_t)c * N + i] = keypoints[2 * (size_t)i + c];
+    }
+    // distinct first poses go to the upload slots behind the ring
+    std::vector<double> table; std::vector<int32_t> idx(std::max(C, 1));
+    for (int i = 0; i < C; ++i) {
+        for (int c = 0; c < 2; ++c) { hc[(size_t)c * C + i] = ck[2 * (size_t)i + c]; hf[(size_t)c * C + i] = cfk[2 * (size_t)i + c]; }
+        const double* p = cposes + 12 * (size_t)i;
+        int found = -1;
+        for (size_t k = 0; k < table.size() / 12 && found < 0; ++k)
+            if (!memcmp(table.data() + 12 * k, p, 96)) found = (int)k;
+        if (found < 0) { found = (int)(table.size() / 12); table.insert(table.end(), p, p + 12); }
+        idx[i] = st->ring + found;
+    }
+    if ((int)(table.size() / 12) > st->P - st->ring) { ctx->last_error = "frame: too many distinct first poses in the uploaded state"; return VO_ERR_BAD_ARG; }
+    ST_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < 3 && N > 0; ++c) ST_CHECK(hipMemcpyAsync(st->L[s] + (size_t)c * cl, hL.data() + (size_t)c * N, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (int c = 0; c < 2 && N > 0; ++c) ST_CHECK(hipMemcpyAsync(st->kp[s] + (size_t)c * cl, hk.data() + (size_t)c * N, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (N > 0) ST_CHECK(hipMemcpyAsync(st->rep[s], repro, (size_t)N * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (int c = 0; c < 2 && C > 0; ++c) {
+        ST_CHECK(hipMemcpyAsync(st->cu[s] + (size_t)c * cc, hc.data() + (size_t)c * C, (size_t)C * 8, hipMemcpyHostToDevice, ctx->stream));
+        ST_CHECK(hipMemcpyAsync(st->cf[s] + (size_t)c * cc, hf.data() + (size_t)c * C, (size_t)C * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (C > 0) {
+        ST_CHECK(hipMemcpyAsync(st->cpose[s], idx.data(), (size_t)C * 4, hipMemcpyHostToDevice, ctx->stream));
+        ST_CHECK(hipMemcpyAsync(st->ctime[s], ctime, (size_t)C * 4, hipMemcpyHostToDevice, ctx->stream));
+        ST_CHECK(hipMemcpyAsync(st->poses + 12 * (size_t)st->ring, table.data(), table.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ST_CHECK(hipStreamSynchronize(ctx->stream));
+    st->nL = N; st->nC = C; st->frame_no = frame_no;
+    return VO_OK;
+}
+
+int vo_frame_get_counts(vo_ctx* ctx, vo_frame_state* st, int* N, int* C) {
+    if (!ctx || !st) return VO_ERR_BAD_ARG;
+    if (N) *N = st->nL;
+    if (C) *C = st->nC;
+    return VO_OK;
+}
+
+int vo_frame_get_state(vo_ctx* ctx, vo_frame_state* st, double* landmarks, double* keypoints, double* repro,
+                       double* ck, double* cfk, double* cposes, int32_t* ctime) {
+    if (!ctx || !st) return VO_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    const int s = st->s, N = st->nL, C = st->nC, cl = st->capL, cc = st->capC;
+    std::vector<double> hL(3 * (size_t)std::max(N, 1)), hk(2 * (size_t)std::max(N, 1)), hc(2 * (size_t)std::max(C, 1)), hf(2 * (size_t)std::max(C, 1)),
+        table(12 * (size_t)st->P);
+    std::vector<int32_t> idx(std::max(C, 1));
+    for (int c = 0; c < 3 && N > 0; ++c) ST_CHECK(hipMemcpyAsync(hL.data() + (size_t)c * N, st->L[s] + (size_t)c * cl, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    for (int c = 0; c < 2 && N > 0; ++c) ST_CHECK(hipMemcpyAsync(hk.data() + (size_t)c * N, st->kp[s] + (size_t)c * cl, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (N > 0 && repro) ST_CHECK(hipMemcpyAsync(repro, st->rep[s], (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    for (int c = 0; c < 2 && C > 0; ++c) {
+        ST_CHECK(hipMemcpyAsync(hc.data() + (size_t)c * C, st->cu[s] + (size_t)c * cc, (size_t)C * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ST_CHECK(hipMemcpyAsync(hf.data() + (size_t)c * C, st->cf[s] + (size_t)c * cc, (size_t)C * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (C > 0) {
+        ST_CHECK(hipMemcpyAsync(idx.data(), st->cpose[s], (size_t)C * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctime) ST_CHECK(hipMemcpyAsync(ctime, st->ctime[s], (size_t)C * 4, hipMemcpyDeviceToHost, ctx->stream));
+        ST_CHECK(hipMemcpyAsync(table.data(), st->poses, table.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ST_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < N; ++i) {
+        if (landmarks) for (int c = 0; c < 3; ++c) landmarks[3 * (size_t)i + c] = hL[(size_t)c * N + i];
+        if (keypoints) for (int c = 0; c < 2; ++c) keypoints[2 * (size_t)i + c] = hk[(size_t)c * N + i];
+    }
+    for (int i = 0; i < C; ++i) {
+        if (ck) for (int c = 0; c < 2; ++c) ck[2 * (size_t)i + c] = hc[(size_t)c * C + i];
+        if (cfk) for (int c = 0; c < 2; ++c) cfk[2 * (size_t)i + c] = hf[(size_t)c * C + i];
+        if (cposes) {
+            const int k = idx[i];
+            if (k < 0 || k >= st->P) { ctx->last_error = "frame: corrupt pose index"; return VO_ERR_HIP; }
+            memcpy(cposes + 12 * (size_t)i, table.data() + 12 * (size_t)k, 96);
+        }
+    }
+    return VO_OK;
+}
+
+int vo_frame_set_image(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device) {
+    if (!ctx || !st || !img) return VO_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    int rc = upload_image(ctx, st, st->cur, img, on_device);
+    if (rc) return rc;
+    st->have_prev = true;
+    return VO_OK;
+}
+
+int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device, double pose43[12], vo_frame_info* info) {
+    if (!ctx || !st || !img || !pose43 || !info) return VO_ERR_BAD_ARG;
+    if (!st->have_prev) { ctx->last_error = "frame: no previous image (vo_frame_set_image)"; return VO_ERR_BAD_ARG; }
+    (void)hipSetDevice(ctx->device);
+    hipStream_t sm = ctx->stream;
+    const vo_frame_opts& o = st->o;
+    const int s = st->s, n = 1 - s, a = st->cur, b = 1 - st->cur;
+    const int cl = st->capL, cc = st->capC, pw = st->PW;
+    const int nL = st->nL, nC = st->nC;
+    const int frame_no = st->frame_no + 1;
+    const int slot = frame_no % st->ring;
+    double* pose_now = st->poses + 12 * (size_t)slot;
+    const double eps = o.klt.eps > 0 ? o.klt.eps : 0.01;
+    int rc;
+    if ((rc = upload_image(ctx, st, b, img, on_device))) return rc;
+    ST_CHECK(hipMemsetAsync(st->counts, 0, 16 * sizeof(int32_t), sm));
+    ST_CHECK(hipMemsetAsync(st->alive, 0, (size_t)pw, sm));
+
+    // [1] :278-281 track the landmarks' keypoints, keep the valid ones in order
+    int M = 0;
+    if (nL > 0) {
+        if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->kp[s], st->kp[s] + cl, nL, o.klt.block_w, o.klt.block_h,
+                                o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + cl, st->valid, st->score, nullptr))) return rc;
+        hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, sm, st->valid, nL, nullptr, st->pos, st->counts + 6);
+        hipLaunchKernelGGL(k_gather_tracked, dim3(blocks(nL)), dim3(256), 0, sm, nL, st->valid, st->pos, st->q, st->q + cl, st->L[s], cl, st->vk, st->vl);
+        ST_CHECK(hipMemcpyAsync(st->h_counts, st->counts + 6, 4, hipMemcpyDeviceToHost, sm));
+        ST_CHECK(hipStreamSynchronize(sm));
+        M = st->h_counts[0];
+    }
+    // [2] :285-289 pose
+    if (M >= 4) {
+        vo_ransac_opts ro = o.pose;
+        ro.seed = o.pose.seed + (uint64_t)frame_no;
+        vo_ransac_work w;
+        if ((rc = vo_int_ransac_work_prepare(ctx, ro.num_hyp, &w))) return rc;
+        vo_strides s2 = {1, cl}, s3 = {1, cl};
+        if ((rc = vo_launch_ransac(ctx, st->vk, s2, st->vl, s3, M, st->K, &ro, nullptr, nullptr, &w, st->rsout, st->inl))) return rc;
+    } else {
+        hipLaunchKernelGGL(k_identity_record, dim3(1), dim3(1), 0, sm, st->rsout, 1);
+    }
+    hipLaunchKernelGGL(k_pose_from_rt, dim3(1), dim3(1), 0, sm, st->rsout, pose_now);
+    // [3] :298-315 reprojection error, strict filter, survivors into the merge arrays
+    if (M > 0) {
+        vo_strides s2 = {1, cl}, s3 = {1, cl};
+        if ((rc = vo_launch_reproj(ctx, st->vk, s2, st->vl, s3, M, pose_now, 0, st->K, st->err))) return rc;
+        hipLaunchKernelGGL(k_flag_less, dim3(blocks(M)), dim3(256), 0, sm, st->err, M, o.max_reproj_err, st->flag);
+        hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, sm, st->flag, M, nullptr, st->pos, st->counts + 7);
+        hipLaunchKernelGGL(k_gather_kept, dim3(blocks(M)), dim3(256), 0, sm, M, st->flag, st->pos, st->vk, st->vl, st->err, cl, pw,
+                           st->wkp, st->wL, st->wrep, st->alive);
+    }
+    // [4] :322 -> :63-151 track + triangulate the candidates, classify, merge in candidate order
+    if (nC > 0) {
+        if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->cu[s], st->cu[s] + cc, nC, o.klt.block_w, o.klt.block_h,
+                                o.klt.max_iters, eps, o.klt.max_bidir_err, st->cq, st->cq + cc, st->cvalid, st->score, nullptr))) return rc;
+        vo_strides c2 = {1, cc}, c3 = {1, cc};
+        if ((rc = vo_launch_triangulate(ctx, st->cf[s], st->cq, c2, st->poses, 0, st->cpose[s], nC, st->P, pose_now, st->K, st->X, c3,
+                                        st->crep, st->cang, st->cok))) return rc;
+        hipLaunchKernelGGL(k_classify, dim3(blocks(nC)), dim3(256), 0, sm, nC, st->cvalid, st->cok, st->crep, st->cang, st->ctime[s],
+                           o.max_reproj_err, o.angular_threshold_deg, o.max_temporal_recall, st->cls, st->keepf);
+        MergeArgs m;
+        m.nC = nC; m.cap = cl; m.PW = pw; m.capC = cc; m.cls = st->cls; m.X = st->X; m.crep = st->crep; m.cq = st->cq;
+        m.wkp = st->wkp; m.wL = st->wL; m.wrep = st->wrep; m.alive = st->alive; m.n0 = st->counts + 7; m.plist = st->plist;
+        m.n_promoted = st->counts + 8;
+        hipLaunchKernelGGL(k_merge, dim3(1), dim3(1024), 0, sm, m);
+        hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, sm, st->keepf, nC, nullptr, st->pos, st->counts + 1);
+        hipLaunchKernelGGL(k_gather_candidates, dim3(blocks(nC)), dim3(256), 0, sm, nC, st->keepf, st->pos, cc, st->cq, st->cf[s],
+                           st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]);
+    }
+    hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, sm, st->alive, pw, nullptr, st->pos, st->counts + 0);
+    hipLaunchKernelGGL(k_gather_landmarks, dim3(blocks(pw)), dim3(256), 0, sm, pw, st->alive, st->pos, pw, cl, st->wkp, st->wL, st->wrep,
+                       st->kp[n], st->L[n], st->rep[n]);
+    // [5] :330-345 new candidates away from every tracked point
+    hipLaunchKernelGGL(k_existing, dim3(blocks(pw)), dim3(256), 0, sm, st->counts, cl, cc, st->kp[n], st->cu[n], st->eu, st->ev);
+    ST_CHECK(hipMemcpyAsync(st->h_counts, st->counts, 2 * 4, hipMemcpyDeviceToHost, sm));
+    ST_CHECK(hipStreamSynchronize(sm));
+    const int nLn = st->h_counts[0], nCk = st->h_counts[1];
+    if (o.sel.keep > 0) {
+        vo_sel_work w;
+        if ((rc = vo_int_sel_work_prepare(ctx, st->nu, st->nv, o.sel.keep, nLn + nCk, o.sel.min_distance, &w))) return rc;
+        if ((rc = vo_launch_select(ctx, st->img[b], st->nu, st->nv, 0, st->eu, st->ev, nLn + nCk, &o.sel, &w, st->su, st->sv, st->slin,
+                                   nullptr, st->counts + 2))) return rc;
+    }
+    hipLaunchKernelGGL(k_append_new, dim3(blocks(std::max(o.sel.keep, 1))), dim3(256), 0, sm, st->counts, cc, st->su, st->sv, slot,
+                       st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]);
+    ST_CHECK(hipGetLastError());
+    ST_CHECK(hipMemcpyAsync(st->h_counts, st->counts, 16 * 4, hipMemcpyDeviceToHost, sm));
+    ST_CHECK(hipMemcpyAsync(st->h_rec, st->rsout, 128, hipMemcpyDeviceToHost, sm));
+    ST_CHECK(hipMemcpyAsync(st->h_rec + 16, pose_now, 96, hipMemcpyDeviceToHost, sm));
+    ST_CHECK(hipStreamSynchronize(sm));
+    int32_t ri[5];
+    memcpy(ri, st->h_rec + 12, sizeof ri);
+    memcpy(pose43, st->h_rec + 16, 96);
+    info->status = ri[0]; info->trials_used = ri[3]; info->n_inliers = ri[4];
+    info->n_landmarks = st->h_counts[0]; info->n_candidates = st->h_counts[3]; info->n_tracked = M;
+    info->n_promoted = st->h_counts[8]; info->n_new = st->h_counts[5]; info->overflow = st->h_counts[4];
+    info->frame_no = frame_no;
+    st->nL = std::min(st->h_counts[0], cl); st->nC = st->h_counts[3];
+    st->s = n; st->cur = b; st->frame_no = frame_no;
+    return VO_OK;
+}
+
+} // extern "C"

@@ -140,3 +140,35 @@ def triangulation_scene(n, seed=8191, K=KITTI_K, nv=376, nu=1241, noise=0.2, n_p
     xy0 = xy0 + r.normal(0, noise, xy0.shape)
     xy1 = xy1 + r.normal(0, noise, xy1.shape)
     return xy0, xy1, poses0, pose1, X
+
+
+def plane_sequence(n_frames, K, nv=240, nu=320, seed=77, depth=12.0, step=(0.12, 0.02, 0.10), yaw_deg=0.15, noise=0.5):
+    """A 3D-consistent sequence for the frame loop (modules/VisualOdometry.m:264-346): a textured
+    fronto-parallel plane Z = depth (world = camera 0) seen by a camera that moves by `step` metres
+    and turns by `yaw_deg` per frame.  Returns frames (uint8), poses (4x3 [R_cw; C] each) and a
+    function lifting frame-0 pixels to their landmarks on the plane."""
+    margin = 96
+    tex = texture(nv, nu, seed, margin=margin)
+    vv, uu = np.mgrid[0:nv, 0:nu].astype(np.float64)
+    Kinv = np.linalg.inv(K)
+    rays = np.stack([uu.ravel(), vv.ravel(), np.ones(uu.size)], 0)
+    r = _rng(seed + 1)
+    frames, poses = [], []
+    for k in range(n_frames):
+        R_cw = rot_y(yaw_deg * k)
+        C = np.array(step, dtype=np.float64) * k
+        d = R_cw.T @ (Kinv @ rays)                      # ray directions in world coordinates
+        lam = (depth - C[2]) / d[2]
+        X = C[:, None] + lam * d                         # intersection with the plane
+        tu = K[0, 0] * X[0] / depth + K[0, 2]            # the plane's texture = frame 0
+        tv = K[1, 1] * X[1] / depth + K[1, 2]
+        img = ndimage.map_coordinates(tex, [tv.reshape(nv, nu) + margin, tu.reshape(nv, nu) + margin], order=3, mode="nearest")
+        if noise > 0:
+            img = img + r.normal(0, noise, img.shape)
+        frames.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+        poses.append(pose43(R_cw, C))
+
+    def lift(u, v):
+        return np.stack([(u - K[0, 2]) / K[0, 0] * depth, (v - K[1, 2]) / K[1, 1] * depth, np.full_like(u, depth, dtype=np.float64)], 1)
+
+    return frames, poses, lift
