@@ -40,6 +40,19 @@ __global__ __launch_bounds__(1024) void k_scan_flags(const uint8_t* __restrict__
     if (tid == 0) *count = base_s;
 }
 
+// the frame's two track calls (:278 landmarks, :71 candidates) share the image pair: one launch
+__global__ void k_concat_points(int nL, int nC, int capL, int capC, const double* kp, const double* cu, double* pin, int PW) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nL) { pin[i] = kp[i]; pin[PW + i] = kp[capL + i]; }
+    else if (i < nL + nC) { const int c = i - nL; pin[i] = cu[c]; pin[PW + i] = cu[capC + c]; }
+}
+__global__ void k_split_candidates(int nL, int nC, int capC, int PW, const double* q, const uint8_t* valid, double* cq, uint8_t* cvalid) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nC) return;
+    cq[c] = q[nL + c]; cq[capC + c] = q[PW + nL + c];
+    cvalid[c] = valid[nL + c];
+}
+
 // landmarks whose keypoint tracked validly (:280-281): (q, L) -> (vk, vl), pitch = capL
 __global__ void k_gather_tracked(int n, const uint8_t* valid, const int32_t* pos, const double* qu, const double* qv,
                                  const double* L, int capL, double* vk, double* vl) {
@@ -97,7 +110,7 @@ __global__ void k_classify(int n, const uint8_t* tracked, const uint8_t* ok, con
 }
 
 // The order-dependent merge of :87-142 over the promotable candidates, in candidate order.
-// One block.  Landmarks are never moved: a replaced landmark (:116-122) is tombstoned, an
+// Landmarks are never moved: a replaced landmark (:116-122) is tombstoned, an
 // accepted one appended (:123-127); the ordered compaction afterwards gives the MATLAB order.
 struct MergeArgs {
     int nC, cap, PW, capC;
@@ -108,65 +121,108 @@ struct MergeArgs {
     int32_t* plist;                 // scratch, nC
     int32_t* n_promoted;
 };
-__global__ __launch_bounds__(1024) void k_merge(MergeArgs a) {
-    __shared__ int wsum[16];
-    __shared__ int s_np, s_alive, s_tot, s_prom;
-    __shared__ double r_val[16];
-    __shared__ int r_idx[16];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) { s_np = 0; s_alive = *a.n0; s_tot = *a.n0; s_prom = 0; }
-    __syncthreads();
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned x) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWMASK, 0xf, false); // lanes without a source read 0
+}
+// maximum over the 64 lanes, result uniform (DPP row operations, as wave_sum in vo_klt.hip)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
+    x = max(x, dpp_u32<0xb1, 0xf>(x));  // quad_perm [1,0,3,2]
+    x = max(x, dpp_u32<0x4e, 0xf>(x));  // quad_perm [2,3,0,1]
+    x = max(x, dpp_u32<0x114, 0xf>(x)); // row_shr:4
+    x = max(x, dpp_u32<0x118, 0xf>(x)); // row_shr:8
+    x = max(x, dpp_u32<0x142, 0xa>(x)); // row_bcast:15
+    x = max(x, dpp_u32<0x143, 0xc>(x)); // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+// One wave: every step is wave-synchronous.  For the usual sizes the reprojection errors, the
+// tombstones and the promotable candidates' errors sit in LDS and the loop touches nothing else:
+// global memory is read before it and the accepted landmarks are written after it, in parallel.
+constexpr int MERGE_LDS = 4096; // landmarks + appended entries that fit the LDS copy (else global arrays)
+constexpr int MERGE_PL = 2048;  // promotable candidates that fit the LDS list (else global arrays)
+__global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
+    __shared__ double s_rep[MERGE_LDS];
+    __shared__ uint8_t s_alv[MERGE_LDS];
+    __shared__ double s_prep[MERGE_PL];
+    __shared__ int32_t s_pidx[MERGE_PL];
+    const int lane = threadIdx.x;
+    const int n0 = *a.n0;
     // ordered list of the promotable candidates
-    for (int i0 = 0; i0 < a.nC; i0 += 1024) {
-        const int i = i0 + tid;
+    int np = 0;
+    for (int i0 = 0; i0 < a.nC; i0 += 64) {
+        const int i = i0 + lane;
         const int f = (i < a.nC && a.cls[i] == 1) ? 1 : 0;
         const unsigned long long bal = __ballot(f);
-        if (lane == 0) wsum[wid] = __popcll(bal);
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) { if (w < wid) woff += wsum[w]; tot += wsum[w]; }
-        const int base = s_np;
-        if (f) a.plist[base + woff + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-        __syncthreads();
-        if (tid == 0) s_np = base + tot;
-        __syncthreads();
+        if (f) a.plist[np + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        np += __popcll(bal);
     }
-    const int np = s_np;
+    __syncthreads();
+    const bool in_lds = a.PW <= MERGE_LDS, pl_lds = np <= MERGE_PL;
+    double* rep = in_lds ? s_rep : a.wrep;
+    uint8_t* alv = in_lds ? s_alv : a.alive;
+    if (in_lds)
+        for (int k = lane; k < n0; k += 64) { s_rep[k] = a.wrep[k]; s_alv[k] = a.alive[k]; }
+    if (pl_lds)
+        for (int j = lane; j < np; j += 64) { const int i = a.plist[j]; s_pidx[j] = i; s_prep[j] = a.crep[i]; }
+    __syncthreads();
+    int alive_n = n0, tot = n0, prom = 0;   // wave-uniform
+    // every lane caches the first maximum (bv at bi) of its share {k = lane mod 64} of the live
+    // landmarks; an edit re-scans only the share it touches
+    double bv = 0; int bi = -1;
+    bool cached = false;
     for (int j = 0; j < np; ++j) {
-        const int i = a.plist[j];
-        const double r = a.crep[i];
-        const int alive_now = s_alive, tot = s_tot; // every thread reads before anyone edits
-        __syncthreads();
-        if (alive_now >= a.cap) {
-            // :89-90 first maximum of reproError over the live landmarks
-            double bv = 0; int bi = -1;
-            for (int k = tid; k < tot; k += 1024)
-                if (a.alive[k]) { const double v = a.wrep[k]; if (bi < 0 || v > bv) { bv = v; bi = k; } }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const double ov = __shfl_xor(bv, d, 64); const int oi = __shfl_xor(bi, d, 64);
-                if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        const double r = pl_lds ? s_prep[j] : a.crep[a.plist[j]];
+        if (alive_n >= a.cap) {
+            if (!cached) {
+                bv = 0; bi = -1;
+                for (int k = lane; k < tot; k += 64)
+                    if (alv[k]) { const double v = rep[k]; if (bi < 0 || v > bv) { bv = v; bi = k; } }
+                cached = true;
             }
-            if (lane == 0) { r_val[wid] = bv; r_idx[wid] = bi; }
-            __syncthreads();
-            if (tid == 0) {
-                double mv = 0; int mi = -1;
-                for (int w = 0; w < 16; ++w)
-                    if (r_idx[w] >= 0 && (mi < 0 || r_val[w] > mv || (r_val[w] == mv && r_idx[w] < mi))) { mv = r_val[w]; mi = r_idx[w]; }
-                if (mi >= 0 && r <= mv) { a.alive[mi] = 0; s_alive = s_alive - 1; }   // :116-122
+            // :89-90 first maximum of reproError: errors are >= 0, so their bit patterns order like
+            // the values; maximum of the high words, then of the low words among those, then the
+            // lowest index among equals
+            const unsigned long long key = bi >= 0 ? (unsigned long long)__double_as_longlong(bv) + 1ull : 0ull;
+            const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+            const unsigned mhi = wave_max_u32(hi);
+            const unsigned mlo = wave_max_u32(hi == mhi ? lo : 0u);
+            const bool win = bi >= 0 && hi == mhi && lo == mlo;
+            const unsigned mix = wave_max_u32(win ? 0xffffffffu - (unsigned)bi : 0u);
+            if (mix != 0u) {
+                const int mi = (int)(0xffffffffu - mix);
+                const double mv = __longlong_as_double((long long)((((unsigned long long)mhi << 32) | mlo) - 1ull));
+                if (r <= mv) {                                                         // :116-122
+                    if (lane == (mi & 63)) {
+                        alv[mi] = 0;
+                        bv = 0; bi = -1;
+                        for (int k = lane; k < tot; k += 64)
+                            if (alv[k]) { const double v = rep[k]; if (bi < 0 || v > bv) { bv = v; bi = k; } }
+                    }
+                    alive_n -= 1;
+                }
             }
         }
-        if (tid == 0 && s_alive < a.cap) {                                             // :123-127
-            const int d = s_tot;
-            a.wL[d] = a.X[i]; a.wL[a.PW + d] = a.X[a.capC + i]; a.wL[2 * a.PW + d] = a.X[2 * a.capC + i];
-            a.wkp[d] = a.cq[i]; a.wkp[a.PW + d] = a.cq[a.capC + i];
-            a.wrep[d] = r;
-            a.alive[d] = 1;
-            s_tot = d + 1; s_alive = s_alive + 1; s_prom = s_prom + 1;
+        if (alive_n < a.cap) {                                                         // :123-127
+            if (lane == (tot & 63)) {
+                rep[tot] = r; alv[tot] = 1;
+                if (cached && (bi < 0 || r > bv)) { bv = r; bi = tot; }
+            }
+            if (lane == 0) a.plist[prom] = pl_lds ? s_pidx[j] : a.plist[j];   // accepted candidates, in order (prom <= j)
+            tot += 1; alive_n += 1; prom += 1;
         }
         __syncthreads();
     }
-    if (tid == 0) *a.n_promoted = s_prom;
+    // the accepted candidates become landmarks n0 .. n0 + prom - 1 of the work arrays
+    for (int k = lane; k < prom; k += 64) {
+        const int i = a.plist[k], d = n0 + k;
+        a.wL[d] = a.X[i]; a.wL[a.PW + d] = a.X[a.capC + i]; a.wL[2 * a.PW + d] = a.X[2 * a.capC + i];
+        a.wkp[d] = a.cq[i]; a.wkp[a.PW + d] = a.cq[a.capC + i];
+        a.wrep[d] = a.crep[i];
+    }
+    if (in_lds)
+        for (int k = lane; k < tot; k += 64) a.alive[k] = s_alv[k];
+    if (lane == 0) *a.n_promoted = prom;
 }
 
 // ordered compaction of the live landmarks into the next state (pitch capL)
@@ -240,7 +296,7 @@ struct vo_frame_state {
     int s;                                  // index of the current state
     double *poses, *K, *rsout;
     // work
-    double *q, *vk, *vl, *err, *cq, *X, *crep, *cang, *wkp, *wL, *wrep;
+    double *pin, *q, *vk, *vl, *err, *cq, *X, *crep, *cang, *wkp, *wL, *wrep;
     float *score, *eu, *ev, *su, *sv;
     uint8_t *valid, *flag, *cvalid, *cok, *cls, *keepf, *alive, *inl;
     int32_t *pos, *plist, *counts, *slin;
@@ -262,20 +318,20 @@ struct Bump {
 };
 void carve(vo_frame_state* st, char* base, size_t* total) {
     Bump b; b.base = base;
-    const size_t cl = st->capL, cc = st->capC, pw = st->PW, mx = std::max(cl, cc);
+    const size_t cl = st->capL, cc = st->capC, pw = st->PW;
     for (int k = 0; k < 2; ++k) {
         st->L[k] = b.take<double>(3 * cl); st->kp[k] = b.take<double>(2 * cl); st->rep[k] = b.take<double>(cl);
         st->cu[k] = b.take<double>(2 * cc); st->cf[k] = b.take<double>(2 * cc);
         st->cpose[k] = b.take<int32_t>(cc); st->ctime[k] = b.take<int32_t>(cc);
     }
     st->poses = b.take<double>(12 * (size_t)st->P); st->K = b.take<double>(9); st->rsout = b.take<double>(16);
-    st->q = b.take<double>(2 * cl); st->vk = b.take<double>(2 * cl); st->vl = b.take<double>(3 * cl); st->err = b.take<double>(cl);
+    st->pin = b.take<double>(2 * pw); st->q = b.take<double>(2 * pw); st->vk = b.take<double>(2 * cl); st->vl = b.take<double>(3 * cl); st->err = b.take<double>(cl);
     st->cq = b.take<double>(2 * cc); st->X = b.take<double>(3 * cc); st->crep = b.take<double>(cc); st->cang = b.take<double>(cc);
     st->wkp = b.take<double>(2 * pw); st->wL = b.take<double>(3 * pw); st->wrep = b.take<double>(pw);
-    st->score = b.take<float>(mx); st->eu = b.take<float>(pw); st->ev = b.take<float>(pw);
+    st->score = b.take<float>(pw); st->eu = b.take<float>(pw); st->ev = b.take<float>(pw);
     const size_t keep = (size_t)std::max(st->o.sel.keep, 1);
     st->su = b.take<float>(keep); st->sv = b.take<float>(keep); st->slin = b.take<int32_t>(keep);
-    st->valid = b.take<uint8_t>(cl); st->flag = b.take<uint8_t>(cl); st->cvalid = b.take<uint8_t>(cc); st->cok = b.take<uint8_t>(cc);
+    st->valid = b.take<uint8_t>(pw); st->flag = b.take<uint8_t>(cl); st->cvalid = b.take<uint8_t>(cc); st->cok = b.take<uint8_t>(cc);
     st->cls = b.take<uint8_t>(cc); st->keepf = b.take<uint8_t>(cc); st->alive = b.take<uint8_t>(pw); st->inl = b.take<uint8_t>(cl);
     st->pos = b.take<int32_t>(pw); st->plist = b.take<int32_t>(cc); st->counts = b.take<int32_t>(16);
     *total = b.off + 256;
@@ -453,14 +509,22 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
     ST_CHECK(hipMemsetAsync(st->counts, 0, 16 * sizeof(int32_t), sm));
     ST_CHECK(hipMemsetAsync(st->alive, 0, (size_t)pw, sm));
 
-    // [1] :278-281 track the landmarks' keypoints, keep the valid ones in order
+    // [1] :278-281 and :71 track the landmarks' keypoints and the candidates in one launch; keep the
+    // validly tracked landmarks in order
     int M = 0;
+    if (nL + nC > 0) {
+        hipLaunchKernelGGL(k_concat_points, dim3(blocks(nL + nC)), dim3(256), 0, sm, nL, nC, cl, cc, st->kp[s], st->cu[s], st->pin, pw);
+        if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->pin, st->pin + pw, nL + nC, o.klt.block_w, o.klt.block_h,
+                                o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, st->score, nullptr))) return rc;
+    }
     if (nL > 0) {
-        if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->kp[s], st->kp[s] + cl, nL, o.klt.block_w, o.klt.block_h,
-                                o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + cl, st->valid, st->score, nullptr))) return rc;
         hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, sm, st->valid, nL, nullptr, st->pos, st->counts + 6);
-        hipLaunchKernelGGL(k_gather_tracked, dim3(blocks(nL)), dim3(256), 0, sm, nL, st->valid, st->pos, st->q, st->q + cl, st->L[s], cl, st->vk, st->vl);
+        hipLaunchKernelGGL(k_gather_tracked, dim3(blocks(nL)), dim3(256), 0, sm, nL, st->valid, st->pos, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl);
         ST_CHECK(hipMemcpyAsync(st->h_counts, st->counts + 6, 4, hipMemcpyDeviceToHost, sm));
+    }
+    if (nC > 0)   // queued before the host waits for the tracked count
+        hipLaunchKernelGGL(k_split_candidates, dim3(blocks(nC)), dim3(256), 0, sm, nL, nC, cc, pw, st->q, st->valid, st->cq, st->cvalid);
+    if (nL > 0) {
         ST_CHECK(hipStreamSynchronize(sm));
         M = st->h_counts[0];
     }
@@ -485,10 +549,8 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
         hipLaunchKernelGGL(k_gather_kept, dim3(blocks(M)), dim3(256), 0, sm, M, st->flag, st->pos, st->vk, st->vl, st->err, cl, pw,
                            st->wkp, st->wL, st->wrep, st->alive);
     }
-    // [4] :322 -> :63-151 track + triangulate the candidates, classify, merge in candidate order
+    // [4] :322 -> :63-151 triangulate the tracked candidates, classify, merge in candidate order
     if (nC > 0) {
-        if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->cu[s], st->cu[s] + cc, nC, o.klt.block_w, o.klt.block_h,
-                                o.klt.max_iters, eps, o.klt.max_bidir_err, st->cq, st->cq + cc, st->cvalid, st->score, nullptr))) return rc;
         vo_strides c2 = {1, cc}, c3 = {1, cc};
         if ((rc = vo_launch_triangulate(ctx, st->cf[s], st->cq, c2, st->poses, 0, st->cpose[s], nC, st->P, pose_now, st->K, st->X, c3,
                                         st->crep, st->cang, st->cok))) return rc;
@@ -498,7 +560,7 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
         m.nC = nC; m.cap = cl; m.PW = pw; m.capC = cc; m.cls = st->cls; m.X = st->X; m.crep = st->crep; m.cq = st->cq;
         m.wkp = st->wkp; m.wL = st->wL; m.wrep = st->wrep; m.alive = st->alive; m.n0 = st->counts + 7; m.plist = st->plist;
         m.n_promoted = st->counts + 8;
-        hipLaunchKernelGGL(k_merge, dim3(1), dim3(1024), 0, sm, m);
+        hipLaunchKernelGGL(k_merge, dim3(1), dim3(64), 0, sm, m);
         hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, sm, st->keepf, nC, nullptr, st->pos, st->counts + 1);
         hipLaunchKernelGGL(k_gather_candidates, dim3(blocks(nC)), dim3(256), 0, sm, nC, st->keepf, st->pos, cc, st->cq, st->cf[s],
                            st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]);

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
     if (tid == 0 && a.counters) atomicAdd(&a.counters[4 * (blockIdx.x & (VO_COUNTER_SHARDS - 1)) + 3], (unsigned long long)min(SC_HB, a.H - h0));
 }
 
-// ---- sequential RANSAC semantics (old/ransacLocalization.m:86-124) as a chunked scan, one wave ----
+// ---- sequential RANSAC semantics (old/ransacLocalization.m:86-124) as a chunked scan, one block ----
 struct BState { int h, s, c; unsigned long long q; };
 
 __device__ __forceinline__ bool improves(int mode, int min_inl, int c, unsigned long long q, const BState& st) {
@@ -391,33 +391,49 @@ struct BestArgs {
     double confidence; double* out; // R_cw(9) t_cw(3) then 5 int32
 };
 
-__global__ __launch_bounds__(64) void k_best(BestArgs a) {
-    const int lane = threadIdx.x;
-    const int per = (a.H + 63) / 64;
-    const int lo = min(lane * per, a.H), hi = min(lo + per, a.H);
-    BState st; st.h = -1; st.s = -1; st.c = 0; st.q = ~0ull;
+__device__ __forceinline__ BState combine(int mode, int min_inl, const BState& earlier, const BState& later) {
+    // state after an earlier span followed by a later span: the later record wins only if it strictly improves
+    const bool later_wins = later.h >= 0 && (earlier.h < 0 || improves(mode, min_inl, later.c, later.q, earlier));
+    return later_wins ? later : earlier;
+}
+__device__ __forceinline__ BState shfl_up_state(const BState& x, int d) {
+    BState o;
+    o.h = __shfl_up(x.h, d, 64); o.s = __shfl_up(x.s, d, 64); o.c = __shfl_up(x.c, d, 64); o.q = __shfl_up(x.q, d, 64);
+    return o;
+}
+
+// One block of BEST_NT threads, each owning a contiguous chunk of hypotheses: local pass, two-level
+// scan of the best-so-far records (wave shuffles, then the 16 wave totals through LDS), then a
+// re-walk of the chunk with the carried-in record that looks for the adaptive stop.
+constexpr int BEST_NT = 1024;
+__global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
+    __shared__ BState s_wave[BEST_NT / 64];
+    __shared__ int s_stop;
+    __shared__ BState s_fin;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int per = (a.H + BEST_NT - 1) / BEST_NT;
+    const int lo = min(tid * per, a.H), hi = min(lo + per, a.H);
+    BState none; none.h = -1; none.s = -1; none.c = 0; none.q = ~0ull;
+    if (tid == 0) s_stop = 0x7fffffff;
+    BState st = none;
     for (int h = lo; h < hi; ++h) {
         int s, c; unsigned long long q;
         hyp_best(a.cnt, a.cost, a.mode, h, s, c, q);
         if (improves(a.mode, a.min_inl, c, q, st)) { st.h = h; st.s = s; st.c = c; st.q = q; }
     }
-    // inclusive scan over lanes with combine(earlier, later) = later if it strictly improves
-    BState inc = st;
+    BState inc = st; // inclusive scan over the lanes of the wave
     for (int d = 1; d < 64; d <<= 1) {
-        BState o;
-        o.h = __shfl_up(inc.h, d, 64); o.s = __shfl_up(inc.s, d, 64); o.c = __shfl_up(inc.c, d, 64);
-        o.q = __shfl_up(inc.q, d, 64);
-        if (lane >= d) {
-            // o = state of the earlier span, inc = state of the later span
-            const bool later_wins = inc.h >= 0 && (o.h < 0 || improves(a.mode, a.min_inl, inc.c, inc.q, o));
-            if (!later_wins) inc = o;
-        }
+        const BState o = shfl_up_state(inc, d);
+        if (lane >= d) inc = combine(a.mode, a.min_inl, o, inc);
     }
-    BState carry;
-    carry.h = __shfl_up(inc.h, 1, 64); carry.s = __shfl_up(inc.s, 1, 64); carry.c = __shfl_up(inc.c, 1, 64);
-    carry.q = __shfl_up(inc.q, 1, 64);
-    if (lane == 0) { carry.h = -1; carry.s = -1; carry.c = 0; carry.q = ~0ull; }
-    // re-walk the chunk with the carried-in state, looking for the adaptive stop
+    if (lane == 63) s_wave[wid] = inc;
+    __syncthreads();
+    BState wcarry = none;
+    for (int w = 0; w < wid; ++w) wcarry = combine(a.mode, a.min_inl, wcarry, s_wave[w]);
+    BState lcarry = shfl_up_state(inc, 1);
+    if (lane == 0) lcarry = none;
+    const BState carry = combine(a.mode, a.min_inl, wcarry, lcarry);
+    // re-walk the chunk with the carried-in record, looking for the adaptive stop
     BState cur = carry;
     int stop = 0x7fffffff;
     if (a.confidence > 0) {
@@ -431,23 +447,17 @@ __global__ __launch_bounds__(64) void k_best(BestArgs a) {
             }
             if (!(N > (double)(h + 2))) { stop = h; break; } // :44 `while num_iterations > i`
         }
-    } else {
-        cur = inc;
+        if (stop != 0x7fffffff) atomicMin(&s_stop, stop);
     }
-    int gstop = stop;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) gstop = min(gstop, __shfl_xor(gstop, d, 64));
-    int owner;
-    if (gstop == 0x7fffffff) owner = 63; // no stop: final state of the last lane (its walk ran to the end)
-    else {
-        const unsigned long long bal = __ballot(stop == gstop);
-        owner = __ffsll((long long)bal) - 1;
-    }
-    if (a.confidence > 0 && gstop == 0x7fffffff) cur = inc; // lanes with empty chunks carry the state through
-    BState fin;
-    fin.h = __shfl(cur.h, owner, 64); fin.s = __shfl(cur.s, owner, 64); fin.c = __shfl(cur.c, owner, 64);
-    fin.q = __shfl(cur.q, owner, 64);
-    if (lane == 0) {
+    __syncthreads();
+    const int gstop = s_stop;
+    // the record at the stop belongs to the thread whose chunk holds it; without a stop it is the
+    // record after every chunk, which the last thread knows
+    const bool owner = gstop == 0x7fffffff ? (tid == BEST_NT - 1) : (stop == gstop);
+    if (owner) s_fin = gstop == 0x7fffffff ? combine(a.mode, a.min_inl, wcarry, inc) : cur;
+    __syncthreads();
+    if (tid == 0) {
+        const BState fin = s_fin;
         int32_t* info = (int32_t*)(a.out + 12);
         const int used = gstop == 0x7fffffff ? a.H : gstop + 1;
         if (fin.h >= 0) {
@@ -517,7 +527,7 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
     BestArgs b;
     b.cnt = w->cnt; b.cost = w->cost; b.Rt = Rt; b.H = H; b.M = M; b.mode = o->mode; b.min_inl = o->min_inliers;
     b.confidence = o->confidence; b.out = (double*)d_out;
-    hipLaunchKernelGGL(k_best, dim3(1), dim3(64), 0, ctx->stream, b);
+    hipLaunchKernelGGL(k_best, dim3(1), dim3(BEST_NT), 0, ctx->stream, b);
     InlArgs in;
     in.xy = d_xy; in.sxy = sxy; in.X = d_X; in.sX = sX; in.M = M; in.K = d_K; in.thr2 = thr2; in.out = (double*)d_out;
     in.inliers = d_inliers;
