@@ -247,45 +247,61 @@ __global__ __launch_bounds__(256) void k_grid_fill(GridArgs a) {
     const int pos = a.offs[c] + atomicAdd(&a.cursor[c], 1);
     a.su[pos] = u; a.sv[pos] = v;
 }
+// kept corners are also appended to klist (any order: the selectUniform rounds do not depend on it),
+// one global atomic per wave
+__device__ __forceinline__ void append_kept(bool k, int i, int32_t* klist, int32_t* nkeep) {
+    const unsigned long long bal = __ballot(k);
+    if (!bal) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == (int)__ffsll((long long)bal) - 1) base = atomicAdd(nkeep, __popcll(bal));
+    base = __shfl(base, (int)__ffsll((long long)bal) - 1, 64);
+    if (k) klist[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+}
 __global__ __launch_bounds__(256) void k_distance(const float* __restrict__ cu, const float* __restrict__ cv,
                                                    const int32_t* __restrict__ m0, GridArgs g, float thr_d2,
-                                                   uint8_t* keep) {
+                                                   uint8_t* keep, int32_t* klist, int32_t* nkeep) {
     const int m = *m0;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    const float pu = cu[i], pv = cv[i];
-    const int c0u = grid_cell1(pu, g.inv_cs, g.gu), c0v = grid_cell1(pv, g.inv_cs, g.gv);
-    bool k = true;
-    for (int dv = -1; dv <= 1 && k; ++dv) {
-        const int cv_ = c0v + dv;
-        if (cv_ < 0 || cv_ >= g.gv) continue;
-        const int ua = max(c0u - 1, 0), ub = min(c0u + 1, g.gu - 1);
-        // the three cells of one grid row are contiguous in the sorted arrays
-        const int j0 = g.offs[cv_ * g.gu + ua];
-        const int j1 = g.offs[cv_ * g.gu + ub] + g.count[cv_ * g.gu + ub];
-        for (int j = j0; j < j1; ++j) {
-            const float dx = pu - g.su[j], dy = pv - g.sv[j];
-            const float d2 = dx * dx + dy * dy;
-            if (d2 < thr_d2) { k = false; break; }
+    bool k = i < m;
+    if (k) {
+        const float pu = cu[i], pv = cv[i];
+        const int c0u = grid_cell1(pu, g.inv_cs, g.gu), c0v = grid_cell1(pv, g.inv_cs, g.gv);
+        for (int dv = -1; dv <= 1 && k; ++dv) {
+            const int cv_ = c0v + dv;
+            if (cv_ < 0 || cv_ >= g.gv) continue;
+            const int ua = max(c0u - 1, 0), ub = min(c0u + 1, g.gu - 1);
+            // the three cells of one grid row are contiguous in the sorted arrays
+            const int j0 = g.offs[cv_ * g.gu + ua];
+            const int j1 = g.offs[cv_ * g.gu + ub] + g.count[cv_ * g.gu + ub];
+            for (int j = j0; j < j1; ++j) {
+                const float dx = pu - g.su[j], dy = pv - g.sv[j];
+                const float d2 = dx * dx + dy * dy;
+                if (d2 < thr_d2) { k = false; break; }
+            }
         }
+        keep[i] = k ? 1 : 0;
     }
-    keep[i] = k ? 1 : 0;
+    append_kept(k, i, klist, nkeep);
 }
-__global__ __launch_bounds__(256) void k_keep_all(const int32_t* __restrict__ m0, uint8_t* keep) {
+__global__ __launch_bounds__(256) void k_keep_all(const int32_t* __restrict__ m0, uint8_t* keep, int32_t* klist, int32_t* nkeep) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < *m0) keep[i] = 1;
+    const bool k = i < *m0;
+    if (k) keep[i] = 1;
+    append_kept(k, i, klist, nkeep);
 }
 
 // ---- N8 selectUniform + ordered output.  Single block; cell tables in global scratch.
 struct UniArgs {
     const float *cu, *cv; const double* metric; const int32_t* lin; const uint8_t* keep; uint8_t* sel;
-    const int32_t* m0; int n_keep, nu, nv, u_is_rows;
+    const int32_t *m0, *nkeep; int n_keep, nu, nv, u_is_rows;
     unsigned long long* cell_key; int32_t* cell_idx;
     int32_t *klist, *kcell; // compact list of the kept corners and their cell in the current round
     float *out_u, *out_v; int32_t* out_lin; double* out_metric; int32_t* out_count;
 };
 
 constexpr int UNI_LDS_CELLS = 2048; // per-round cell tables live in LDS up to this many cells
+constexpr int UNI_KPT = 16;          // kept corners a thread can hold in registers across the rounds
 
 // floor((double)c * cells / n) without a division: the product is exact in double (24 + 13 bits),
 // a float estimate is corrected by exact integer-valued comparisons.  Identical to the oracle's
@@ -305,20 +321,95 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
     __shared__ unsigned long long s_key[UNI_LDS_CELLS];
     __shared__ int s_idx[UNI_LDS_CELLS];
     const int t = threadIdx.x, m = *a.m0;
-    if (t == 0) { s_nlist = 0; s_selected = 0; }
-    __syncthreads();
-    // compact the corners that survived the distance filter (order is irrelevant to the rounds)
-    for (int i = t; i < m; i += 1024) {
-        a.sel[i] = 0;
-        if (a.keep[i]) a.klist[atomicAdd(&s_nlist, 1)] = i;
-    }
-    __threadfence_block();
-    __syncthreads();
-    const int nl = s_nlist;
-    if (t == 0) s_remaining = nl;
+    const int nl = *a.nkeep;       // corners that survived the distance filter, compacted by k_distance
+    if (t == 0) { s_selected = 0; s_remaining = nl; s_nlist = 0; }
     __syncthreads();
     const long H = a.u_is_rows ? a.nu : a.nv, W = a.u_is_rows ? a.nv : a.nu;
     const float inv_nu = 1.0f / (float)a.nu, inv_nv = 1.0f / (float)a.nv;
+    // A round has at most `want` <= n_keep cells.  When the cell tables fit LDS and a thread's share
+    // of the kept corners fits its registers, the rounds touch neither L2 nor HBM.
+    const bool fast = nl <= 1024 * UNI_KPT && a.n_keep <= UNI_LDS_CELLS - 1 && m <= 0x1ffff;
+    if (fast) {
+        // per corner: coordinates, metric key, and one packed word: index (bits 0-16, corners < 2^17 by
+        // the capacity rule n/4+16 is checked on the host), this round's cell (17-27), selected (31)
+        float fu[UNI_KPT], fv[UNI_KPT];
+        unsigned long long fk[UNI_KPT];
+        unsigned fp[UNI_KPT];
+        constexpr unsigned NONE = 0xffffffffu, IDX = 0x1ffffu, CELL_NONE = 0x7ffu;
+#pragma unroll
+        for (int k = 0; k < UNI_KPT; ++k) {
+            const int e = t + 1024 * k;
+            fp[k] = NONE; fu[k] = fv[k] = 0.0f; fk[k] = 0ull;
+            if (e < nl) {
+                const int i = a.klist[e];
+                fp[k] = (unsigned)i | (CELL_NONE << 17); fu[k] = a.cu[i]; fv[k] = a.cv[i];
+                fk[k] = (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull;
+            }
+        }
+        while (true) {
+            const int selected = s_selected, remaining = s_remaining;
+            if (!(selected < a.n_keep && remaining > 0)) break;
+            const long want = a.n_keep - selected;
+            long x = (want * H) / W, h = 0;
+            while ((h + 1) * (h + 1) <= x) ++h;
+            if (h < 1) h = 1;
+            if (h > want) h = want;
+            long w = (h * W) / H; if (w < 1) w = 1; if (h * w > want) w = want / h;
+            const int cells_u = (int)(a.u_is_rows ? h : w), cells_v = (int)(a.u_is_rows ? w : h);
+            const int nc = cells_u * cells_v;
+            for (int k = t; k < nc; k += 1024) { s_key[k] = 0ull; s_idx[k] = 0x7fffffff; }
+            if (t == 0) s_round_sel = 0;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < UNI_KPT; ++k) { // phase 1: per-cell maximum metric
+                if (fp[k] == NONE || (fp[k] >> 31)) continue;
+                const int bu = clampi(cell_exact(fu[k], cells_u, a.nu, inv_nu), 0, cells_u - 1);
+                const int bv = clampi(cell_exact(fv[k], cells_v, a.nv, inv_nv), 0, cells_v - 1);
+                const unsigned cell = (unsigned)(bv * cells_u + bu);
+                fp[k] = (fp[k] & IDX) | (cell << 17);
+                atomicMax(&s_key[cell], fk[k]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < UNI_KPT; ++k) { // phase 2: lowest index among the maxima
+                if (fp[k] == NONE || (fp[k] >> 31)) continue;
+                const unsigned cell = (fp[k] >> 17) & CELL_NONE;
+                if (s_key[cell] == fk[k]) atomicMin(&s_idx[cell], (int)(fp[k] & IDX));
+            }
+            __syncthreads();
+            int got = 0;
+#pragma unroll
+            for (int k = 0; k < UNI_KPT; ++k) {
+                if (fp[k] == NONE || (fp[k] >> 31)) continue;
+                const unsigned cell = (fp[k] >> 17) & CELL_NONE;
+                if (s_idx[cell] == (int)(fp[k] & IDX)) { fp[k] |= 0x80000000u; ++got; }
+            }
+            if (got) atomicAdd(&s_round_sel, got);
+            __syncthreads();
+            if (t == 0) { s_selected += s_round_sel; s_remaining -= s_round_sel; }
+            __syncthreads();
+        }
+        // output in ascending corner index: the selected corners (<= n_keep <= UNI_LDS_CELLS) go to
+        // LDS, each finds its rank by counting the smaller indices
+#pragma unroll
+        for (int k = 0; k < UNI_KPT; ++k)
+            if (fp[k] != NONE && (fp[k] >> 31)) s_idx[atomicAdd(&s_nlist, 1)] = (int)(fp[k] & IDX);
+        __syncthreads();
+        const int S = s_nlist;
+        for (int e = t; e < S; e += 1024) {
+            const int i = s_idx[e];
+            int pos = 0;
+            for (int j = 0; j < S; ++j) pos += s_idx[j] < i ? 1 : 0;
+            a.out_u[pos] = a.cu[i]; a.out_v[pos] = a.cv[i];
+            if (a.out_lin) a.out_lin[pos] = a.lin[i];
+            if (a.out_metric) a.out_metric[pos] = a.metric[i];
+        }
+        if (t == 0) *a.out_count = S;
+        return;
+    }
+    for (int i = t; i < m; i += 1024) a.sel[i] = 0;
+    __threadfence_block();
+    __syncthreads();
     while (true) {
         const int selected = s_selected, remaining = s_remaining;
         if (!(selected < a.n_keep && remaining > 0)) break;
@@ -536,9 +627,10 @@ int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is
     hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, ctx->stream, w->resp, nu, nv, w->maxbits,
                        o->min_quality, 1, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric);
     const int dblk = (w->cap + 255) / 256;
+    VO_HIP_CHECK(ctx, hipMemsetAsync(w->m0 + 1, 0, sizeof(int32_t), ctx->stream)); // number of kept corners
     const float thr_d2 = d2_threshold((float)o->min_distance);
     if (n_exist == 0 || !(thr_d2 > 0.0f)) {
-        hipLaunchKernelGGL(k_keep_all, dim3(dblk), dim3(256), 0, ctx->stream, w->m0, w->keep);
+        hipLaunchKernelGGL(k_keep_all, dim3(dblk), dim3(256), 0, ctx->stream, w->m0, w->keep, w->klist, w->m0 + 1);
     } else {
         GridArgs g;
         g.eu = d_eu; g.ev = d_ev; g.ne = n_exist; g.inv_cs = 1.0f / w->grid_cs; g.gu = w->grid_gu; g.gv = w->grid_gv;
@@ -549,10 +641,10 @@ int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is
         hipLaunchKernelGGL(k_grid_count, dim3(eblk), dim3(256), 0, ctx->stream, g);
         hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, g.count, ncell, g.offs, w->grid_total, 0x7fffffff);
         hipLaunchKernelGGL(k_grid_fill, dim3(eblk), dim3(256), 0, ctx->stream, g);
-        hipLaunchKernelGGL(k_distance, dim3(dblk), dim3(256), 0, ctx->stream, w->lu, w->lv, w->m0, g, thr_d2, w->keep);
+        hipLaunchKernelGGL(k_distance, dim3(dblk), dim3(256), 0, ctx->stream, w->lu, w->lv, w->m0, g, thr_d2, w->keep, w->klist, w->m0 + 1);
     }
     UniArgs a;
-    a.cu = w->lu; a.cv = w->lv; a.metric = w->metric; a.lin = w->lin; a.keep = w->keep; a.sel = w->sel; a.m0 = w->m0;
+    a.cu = w->lu; a.cv = w->lv; a.metric = w->metric; a.lin = w->lin; a.keep = w->keep; a.sel = w->sel; a.m0 = w->m0; a.nkeep = w->m0 + 1;
     a.n_keep = o->keep; a.nu = nu; a.nv = nv; a.u_is_rows = u_is_rows;
     a.cell_key = w->cell_key; a.cell_idx = w->cell_idx; a.klist = w->klist; a.kcell = w->kcell;
     a.out_u = d_out_u; a.out_v = d_out_v; a.out_lin = d_out_lin; a.out_metric = d_out_metric; a.out_count = d_out_count;
