@@ -39,25 +39,31 @@ def cpu_baseline(args, frames, budget_s=12.0, max_frames=24):
     xy, X, *_ = synth.pnp_scene(nl)
     xy0, xy1, poses0, pose1, _ = synth.triangulation_scene(args.keypoints - nl)
     eu, ev = pu.astype("float32"), pv.astype("float32")
-    parts = {"klt": 0.0, "ransac": 0.0, "triangulate": 0.0, "select": 0.0}
-    done = 0
-    t_all = time.perf_counter()
-    while done < max_frames and (done == 0 or time.perf_counter() - t_all < budget_s):
-        fa, fb = frames[done % (len(frames) - 1)], frames[done % (len(frames) - 1) + 1]
-        t0 = time.perf_counter()
-        oracle.klt_track(fa, fb, pu, pv, threads=threads)
-        t1 = time.perf_counter()
-        oracle.p3p_ransac(xy, X, synth.KITTI_K, num_hyp=args.hyp, mode=1, min_inliers=4, threads=threads)
-        t2 = time.perf_counter()
-        oracle.triangulate(xy0, xy1, poses0, pose1, synth.KITTI_K)
-        t3 = time.perf_counter()
-        oracle.select_candidates(fb, eu, ev, keep=100)
-        t4 = time.perf_counter()
-        parts["klt"] += t1 - t0; parts["ransac"] += t2 - t1; parts["triangulate"] += t3 - t2; parts["select"] += t4 - t3
-        done += 1
-    total = time.perf_counter() - t_all
+    def run(n_threads, budget, max_n):
+        parts = {"klt": 0.0, "ransac": 0.0, "triangulate": 0.0, "select": 0.0}
+        done = 0
+        t_all = time.perf_counter()
+        while done < max_n and (done == 0 or time.perf_counter() - t_all < budget):
+            fa, fb = frames[done % (len(frames) - 1)], frames[done % (len(frames) - 1) + 1]
+            t0 = time.perf_counter()
+            oracle.klt_track(fa, fb, pu, pv, threads=n_threads)
+            t1 = time.perf_counter()
+            oracle.p3p_ransac(xy, X, synth.KITTI_K, num_hyp=args.hyp, mode=1, min_inliers=4, threads=n_threads)
+            t2 = time.perf_counter()
+            oracle.triangulate(xy0, xy1, poses0, pose1, synth.KITTI_K)
+            t3 = time.perf_counter()
+            oracle.select_candidates(fb, eu, ev, keep=100)
+            t4 = time.perf_counter()
+            parts["klt"] += t1 - t0; parts["ransac"] += t2 - t1; parts["triangulate"] += t3 - t2; parts["select"] += t4 - t3
+            done += 1
+        return done, time.perf_counter() - t_all, parts
+
+    done, total, parts = run(threads, budget_s, max_frames)
+    d1, t1s, _ = run(1, 0.0, 1)          # also single-threaded, one whole frame
     return {"value": args.keypoints * done / total, "unit": "keypoints/s", "cores": threads, "kind": "port",
             "frames_per_s": done / total,
+            "single_thread": {"value": args.keypoints * d1 / t1s, "unit": "keypoints/s", "frames_per_s": d1 / t1s,
+                              "sample": f"{d1} whole frame in {t1s:.1f} s on 1 thread"},
             "sample": f"oracle (C, -O2, OpenMP {threads} threads; triangulation and selection single-threaded): {done} whole "
                       f"frame(s) of the bench workload in {total:.1f} s (KLT {parts['klt']:.1f} s, RANSAC {parts['ransac']:.1f} s, "
                       f"triangulation {parts['triangulate']:.1f} s, selection {parts['select']:.1f} s), nothing scaled"}
