@@ -126,6 +126,22 @@ def test_klt_images_smaller_than_the_patch(ctx, nv, nu):
         assert np.hypot(qu - ou, qv - ov)[both].max() < PX_TOL
 
 
+@pytest.mark.parametrize("nv,nu,n", [(600, 800, 2000), (768, 1024, 5000)])
+def test_klt_malaga_shapes(ctx, nv, nu, n):
+    """BASELINE configs on the Malaga shapes (utils/dataLoaderMalaga.m:54-55 loads 800 x 600; BASELINE
+    quotes 1024 x 768): all n points on the GPU, the first 300 also by the oracle."""
+    img1, img2, truth = synth.frame_pair(nv=nv, nu=nu, seed=21, shift=(-4.1, 2.7), zoom=0.003, noise=1.0)
+    pu, pv = synth.keypoints(n, nv=nv, nu=nu, seed=22)
+    qu, qv, valid, score = klt_gpu(img1, img2, pu, pv, 4, 41, 41, 50, 2.0)
+    tu, tv = truth(pu, pv)
+    err = np.hypot(qu - tu, qv - tv)
+    assert valid.mean() > 0.99 and np.percentile(err[valid], 99) < 0.1
+    m = 300
+    ou, ov, ovalid, *_ = oracle.klt_track(img1, img2, pu[:m], pv[:m], threads=8)
+    both = valid[:m] & ovalid
+    assert (valid[:m] == ovalid).mean() > 0.99 and np.hypot(qu[:m] - ou, qv[:m] - ov)[both].max() < PX_TOL
+
+
 # ---------------------------------------------------------------- selection
 def sel_gpu(img, eu, ev, col_major, **kw):
     """internal-coordinate call in either layout; returns u, v, lin, metric like the oracle."""
