@@ -237,11 +237,13 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             // sum J*(Tu,Tv) is bilinear in the sub-pixel fractions: inside one pixel cell it is the
             // interpolation of the four integer-offset correlations c[dv][du] = sum P(x+du, y+dv)*(Tu,Tv).
             // They are computed once per visited cell; an iteration inside the cell is scalar work.
-            float cu00 = 0, cu10 = 0, cu01 = 0, cu11 = 0, cv00 = 0, cv10 = 0, cv01 = 0, cv11 = 0;
+            // residual inside the cell: B = k0 - fu*ka - fv*(kb + fu*kc), per gradient
+            float ku0 = 0, kua = 0, kub = 0, kuc = 0, kv0 = 0, kva = 0, kvb = 0, kvc = 0;
+            const float fibu = (float)ibu, fibv = (float)ibv;
             for (int it = 0; it < a.max_iters; ++it) {
                 const float tu = fbu + du, tv = fbv + dv;
-                const float cu0 = ((float)ibu + tu) * sf, cv0 = ((float)ibv + tv) * sf; // level-0 position (N4 lost test)
-                if (!(cu0 >= 0.0f && cu0 <= umax && cv0 >= 0.0f && cv0 <= vmax)) {
+                const float cu0 = (fibu + tu) * sf, cv0 = (fibv + tv) * sf; // level-0 position (N4 lost test)
+                if (__builtin_amdgcn_ballot_w64(!(cu0 >= 0.0f && cu0 <= umax && cv0 >= 0.0f && cv0 <= vmax))) {
                     flags |= 1;
                     break;
                 }
@@ -277,20 +279,21 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                             }
                         }
                     }
-                    cu00 = wave_sum(su00); cu10 = wave_sum(su10); cu01 = wave_sum(su01); cu11 = wave_sum(su11);
-                    cv00 = wave_sum(sv00); cv10 = wave_sum(sv10); cv01 = wave_sum(sv01); cv11 = wave_sum(sv11);
+                    const float cu00 = wave_sum(su00), cu10 = wave_sum(su10), cu01 = wave_sum(su01), cu11 = wave_sum(su11);
+                    const float cv00 = wave_sum(sv00), cv10 = wave_sum(sv10), cv01 = wave_sum(sv01), cv11 = wave_sum(sv11);
+                    ku0 = CTu - cu00; kua = cu10 - cu00; kub = cu01 - cu00; kuc = (cu11 - cu10) - kub;
+                    kv0 = CTv - cv00; kva = cv10 - cv00; kvb = cv01 - cv00; kvc = (cv11 - cv10) - kvb;
                     cell = true; ciu = iu; civ = iv;
                     ++cells;
                 }
-                const float fu = unif(tu - flu), fv = unif(tv - flv);
-                const float hu0 = cu00 + fu * (cu10 - cu00), hu1 = cu01 + fu * (cu11 - cu01);
-                const float hv0 = cv00 + fu * (cv10 - cv00), hv1 = cv01 + fu * (cv11 - cv01);
-                const float Bu = CTu - (hu0 + fv * (hu1 - hu0)), Bv = CTv - (hv0 + fv * (hv1 - hv0));
+                const float fu = tu - flu, fv = tv - flv;
+                const float Bu = (ku0 - fu * kua) - fv * (kub + fu * kuc);
+                const float Bv = (kv0 - fu * kva) - fv * (kvb + fu * kvc);
                 ++iters;
-                const float ddu = unif(iuu * Bu + iuv * Bv);
-                const float ddv = unif(iuv * Bu + ivv * Bv);
-                du = unif(du + ddu); dv = unif(dv + ddv);
-                if (ddu * ddu + ddv * ddv < a.eps2) break;
+                const float ddu = iuu * Bu + iuv * Bv;
+                const float ddv = iuv * Bu + ivv * Bv;
+                du += ddu; dv += ddv;
+                if (__builtin_amdgcn_ballot_w64(ddu * ddu + ddv * ddv < a.eps2)) break;
             }
             if (l == 0) { staged0 = staged; pou0 = pou; pov0 = pov; }
         }
