@@ -73,6 +73,46 @@ __device__ __forceinline__ float wave_sum(float x) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 
+// ---- several wave sums at once.  A butterfly that halves the number of live values at every
+// step: lanes with bit k of the lane index clear keep one value of a pair, lanes with it set the
+// other, and each adds its partner lane's share.  After three steps lane l holds value (l & 7)
+// summed over 8 lanes; one row rotation, one 16-lane and one 32-lane swap (gfx950 permlane swaps)
+// complete the sums in every lane.  8 values cost 26 VALU + 8 readlanes instead of 8 x (6 + 1).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float sel_lanes(float if_set, float if_clear, unsigned long long lanes) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(lanes));
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ float merge_pair(float a, float b, unsigned long long lanes) {
+    // lanes clear: a summed over the pair of lanes; lanes set: b summed over the pair
+    return sel_lanes(b, a, lanes) + dpp_mov<CTRL, 0xf>(sel_lanes(a, b, lanes));
+}
+template <int N>
+__device__ __forceinline__ void wave_sums(const float (&v)[N], float (&out)[N]) {
+    static_assert(N >= 5 && N <= 8, "wave_sums handles 5..8 values");
+    constexpr unsigned long long B0 = 0xaaaaaaaaaaaaaaaaull, B1 = 0xccccccccccccccccull, B2 = 0xf0f0f0f0f0f0f0f0ull;
+    float w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float a = 2 * k < N ? v[2 * k] : 0.0f, b = 2 * k + 1 < N ? v[2 * k + 1] : 0.0f;
+        w[k] = 2 * k < N ? merge_pair<0xb1>(a, b, B0) : 0.0f;      // quad_perm [1,0,3,2]
+    }
+    const float x0 = merge_pair<0x4e>(w[0], w[1], B1);                 // quad_perm [2,3,0,1]
+    const float x1 = merge_pair<0x4e>(w[2], w[3], B1);
+    float y = merge_pair<0x124>(x0, x1, B2);                           // row_ror:4
+    y += dpp_mov<0x128, 0xf>(y);                                       // row_ror:8: the whole row of 16
+    const unsigned yb = (unsigned)__float_as_int(y);
+    const u32x2 r16 = __builtin_amdgcn_permlane16_swap(yb, yb, false, false);
+    const float z = __int_as_float((int)r16.x) + __int_as_float((int)r16.y);
+    const unsigned zb = (unsigned)__float_as_int(z);
+    const u32x2 r32 = __builtin_amdgcn_permlane32_swap(zb, zb, false, false);
+    const float t = __int_as_float((int)r32.x) + __int_as_float((int)r32.y);
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), k));
+}
+
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // pyramid geometry of level l (wave-uniform scalar arithmetic; same rule as frame_prepare)
@@ -212,8 +252,10 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             ++setups;
         }
         // sums of the x8 gradients: G = sums / 64
-        const double Guu = (double)wave_sum(sxx) * 0.015625, Guv = (double)wave_sum(sxy) * 0.015625, Gvv = (double)wave_sum(syy) * 0.015625;
-        const float CTu = wave_sum(ctu), CTv = wave_sum(ctv);
+        float s5in[5] = {sxx, sxy, syy, ctu, ctv}, s5[5];
+        wave_sums<5>(s5in, s5);
+        const double Guu = (double)s5[0] * 0.015625, Guv = (double)s5[1] * 0.015625, Gvv = (double)s5[2] * 0.015625;
+        const float CTu = s5[3], CTv = s5[4];
         const double dif = Guu - Gvv;
         // mineig(G) / npx >= VO_MIN_EIG without the division: 2 * mineig(G) >= 2 * npx * VO_MIN_EIG
         const double mineig2 = (Guu + Gvv) - sqrt(dif * dif + 4.0 * (Guv * Guv));
@@ -279,8 +321,10 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                             }
                         }
                     }
-                    const float cu00 = wave_sum(su00), cu10 = wave_sum(su10), cu01 = wave_sum(su01), cu11 = wave_sum(su11);
-                    const float cv00 = wave_sum(sv00), cv10 = wave_sum(sv10), cv01 = wave_sum(sv01), cv11 = wave_sum(sv11);
+                    float c8in[8] = {su00, su10, su01, su11, sv00, sv10, sv01, sv11}, c8[8];
+                    wave_sums<8>(c8in, c8);
+                    const float cu00 = c8[0], cu10 = c8[1], cu01 = c8[2], cu11 = c8[3];
+                    const float cv00 = c8[4], cv10 = c8[5], cv01 = c8[6], cv11 = c8[7];
                     ku0 = CTu - cu00; kua = cu10 - cu00; kub = cu01 - cu00; kuc = (cu11 - cu10) - kub;
                     kv0 = CTv - cv00; kva = cv10 - cv00; kvb = cv01 - cv00; kvc = (cv11 - cv10) - kvb;
                     cell = true; ciu = iu; civ = iv;
