@@ -113,6 +113,13 @@ __device__ __forceinline__ void wave_sums(const float (&v)[N], float (&out)[N]) 
     for (int k = 0; k < N; ++k) out[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), k));
 }
 
+// x where the lane's window-mask bit is set, +0.0f elsewhere: the bit is extracted sign-extended to an
+// all-ones / all-zero word and ANDed in -- no per-pixel lane masks in SGPRs
+__device__ __forceinline__ int mask_word(unsigned mlo, unsigned mhi, int bit) { // bit: a constant after unrolling
+    return __builtin_amdgcn_sbfe((int)(bit < 32 ? mlo : mhi), (unsigned)(bit & 31), 1u); // v_bfe_i32: -1 or 0
+}
+__device__ __forceinline__ float and_bits(float x, int m) { return __int_as_float(__float_as_int(x) & m); }
+
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // pyramid geometry of level l (wave-uniform scalar arithmetic; same rule as frame_prepare)
@@ -215,6 +222,10 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             // exactly, into G and the 2x2 inverse below).
             float E[3][BW + 2];
             float hp[BW + 2];
+            // opaque per-level copies: the mask words are re-extracted at each use (one v_bfe_i32) instead
+            // of living in 30 registers across the kernel
+            unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
+            asm volatile("" : "+v"(mlo), "+v"(mhi));
 #pragma unroll
             for (int r = 0; r < BH + 3; ++r) {
                 float p[BW + 3];
@@ -239,11 +250,11 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                     }
 #pragma unroll
                     for (int i = 0; i < BW; ++i) {
-                        const bool in = (mask >> (j * BW + i)) & 1ull;
+                        const int in = mask_word(mlo, mhi, j * BW + i);
                         const float tu = VS[i + 2] - VS[i];
                         const float tv = (VD[i] + 2.0f * VD[i + 1]) + VD[i + 2];
-                        Tu[j][i] = in ? tu : 0.0f;
-                        Tv[j][i] = in ? tv : 0.0f;
+                        Tu[j][i] = and_bits(tu, in);
+                        Tv[j][i] = and_bits(tv, in);
                         sxx += Tu[j][i] * Tu[j][i]; sxy += Tu[j][i] * Tv[j][i]; syy += Tv[j][i] * Tv[j][i];
                         ctu += e1[i + 1] * Tu[j][i]; ctv += e1[i + 1] * Tv[j][i];
                     }
@@ -385,6 +396,8 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
         const int base = lbase + LK_M * PW + LK_M;
         float ssd = 0;
         float hp[BW];
+        unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
+        asm volatile("" : "+v"(mlo), "+v"(mhi));
 #pragma unroll
         for (int r = 0; r < BH + 1; ++r) {
             float p[BW + 1];
@@ -395,9 +408,9 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             if (r > 0) {
 #pragma unroll
                 for (int c = 0; c < BW; ++c) {
-                    const bool in = (mask >> ((r - 1) * BW + c)) & 1ull;
-                    const float e = (hp[c] + fv * (p[c] - hp[c])) - J[r - 1][c];
-                    ssd += in ? e * e : 0.0f;
+                    const int in = mask_word(mlo, mhi, (r - 1) * BW + c);
+                    const float e = and_bits((hp[c] + fv * (p[c] - hp[c])) - J[r - 1][c], in);
+                    ssd += e * e;
                 }
             }
 #pragma unroll
