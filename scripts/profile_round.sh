@@ -9,10 +9,11 @@ O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/repo_prof && cp -r $R /tmp/repo_prof && cd /tmp/repo_prof
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 50 --warmup 5 --no-cpu > $O/bench_under_rocprof.json 2> $O/trace.log
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 50 --warmup 5 --no-cpu --no-frame-loop > $O/bench_under_rocprof.json 2> $O/trace.log
 pmc() { n=$1; shift
   timeout -s KILL 90 rocprofv3 --pmc "$@" --output-format csv -d $O/$n -- python3 scripts/klt_only.py 50000 3 > $O/$n.log 2>&1
 }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/frame_trace -- python3 scripts/frame_only.py > $O/frame_loop.log 2> $O/frame_trace.log
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc sqa SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY
@@ -20,6 +21,7 @@ pmc sqb SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_
 pmc tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
 cd $R
 cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
+cp $(find $O/frame_trace -name "*kernel_stats.csv") $O/frame_loop_kernel_stats.csv
 python3 scripts/pmc_summary.py k_lk $(find $O -name "*counter_collection.csv") > $O/k_lk_pmc.txt
 timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 > $O/bench.json
 cat $O/k_lk_pmc.txt; head -8 $O/kernel_stats.csv | cut -c1-160; cat $O/bench.json
