@@ -145,3 +145,41 @@ def test_device_images_and_kitti_shape(ctx):
         assert_states_match(g, st)
         st = g                                   # follow the device's own chain
     loop.close()
+
+
+def test_merge_beyond_the_lds_copies(ctx, sequence):
+    """2600 promotable candidates against a landmark cap of 5000 + 3000 candidates: the merge kernel's
+    LDS copies (4096 entries, 2048 promotable) do not fit, so its global-array paths run; then the same
+    candidates against a cap of 150, where almost every one replaces the worst landmark."""
+    frames, poses, lift = sequence
+    k = 8
+    rng = np.random.default_rng(5)
+    n_c = 2600
+    # candidates seen first in frame 0 and now at their true position in frame k-1
+    u0 = rng.uniform(30, 290, n_c); v0 = rng.uniform(30, 210, n_c)
+    X = lift(u0, v0)
+    R, C = poses[k - 1][:3], poses[k - 1][3]
+    uv, z = synth.project(K, R, C, X)
+    ok = (uv[:, 0] > 25) & (uv[:, 0] < 295) & (uv[:, 1] > 25) & (uv[:, 1] < 215)
+    st = start_state(frames[k - 1], lambda a, b: synth_lift_at(poses[k - 1], a, b), n=140)
+    st.candidate_keypoints = uv[ok]
+    st.candidate_first_keypoints = np.stack([u0, v0], 1)[ok]
+    st.candidate_first_poses = np.repeat(poses[0][None], ok.sum(), 0)
+    st.candidate_time_indxs = -np.full(ok.sum(), k - 1, np.int64)
+    assert ok.sum() > 2200
+    for cap in (5000, 150):
+        loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=cap, maxCandidates=3000, ctx=ctx)
+        loop.set_state(st, frames[k - 1], frame_no=k - 1)
+        gpose, gstatus, ginfo = loop.processFrame(frames[k])
+        o, pose, status, info = vo_frame.process_frame(frames[k - 1], frames[k], st, K, k, maxNumLandmarks=cap)
+        assert gstatus == status == 0 and ginfo["n_promoted"] == info["promoted"] > (2000 if cap == 5000 else 100)
+        assert_states_match(loop.get_state(), o)
+        loop.close()
+
+
+def synth_lift_at(pose, u, v, depth=12.0):
+    """landmarks on the plane Z = depth seen at pixel (u, v) from `pose` ([R_cw; C])"""
+    R, C = pose[:3], pose[3]
+    d = R.T @ (np.linalg.inv(K) @ np.stack([u, v, np.ones_like(u)]))
+    lam = (depth - C[2]) / d[2]
+    return (C[:, None] + lam * d).T
