@@ -173,6 +173,20 @@ int vo_p3p_ransac(vo_ctx* ctx, vo_layout lay, const double* img_pts, const doubl
  * poses n x 4 x 12 ([C(3) R(9 row-major, cam->world)] per solution) */
 int vo_p3p_batch(vo_ctx* ctx, const double* world_pts, const double* bearings, int n, double* out_poses);
 
+/* Relative-pose step of the bootstrap: estimateEssentialMatrix(p0, p1, cameraParams, 'MaxNumTrials', n,
+ * 'Confidence', c, 'MaxDistance', d) -- modules/bootstrap.m:76-79.  MSAC around the normalised
+ * eight-point algorithm (the toolbox's solver is closed; definition N10 in oracle/vo_oracle.h).
+ * pts0 / pts1: M x 2 pixel coordinates in K's origin; opts->max_reproj_err carries MaxDistance (Sampson
+ * distance, pixels^2), opts->min_inliers the least inlier count of a winning hypothesis.  out_E: 3 x 3 with
+ * x1' E x0 = 0 on K^-1-normalised points, singular values (1, 1, 0).  info->status 0 ok / 1 fewer than 8
+ * correspondences / 2 no hypothesis qualified.  sample_idx (optional) H x 8, hyp_E_in (optional) H x 9
+ * row-major hypotheses to score instead of sampling; hyp_counts / hyp_costs (H) and hyp_E_out (H x 9)
+ * optional inspection outputs. */
+int vo_essential_ransac(vo_ctx* ctx, vo_layout lay, const double* pts0, const double* pts1, int M, const double* K,
+                        const vo_ransac_opts* opts, const int32_t* sample_idx, const double* hyp_E_in, double* out_E,
+                        uint8_t* out_inliers, vo_ransac_info* info, int32_t* hyp_counts, uint64_t* hyp_costs,
+                        double* hyp_E_out);
+
 /* ==== device-pointer entry points (inputs/outputs resident in HBM; asynchronous on the ctx
  * stream).  Internal convention: image = nv rows of nu contiguous bytes, (u,v) zero-based;
  * points structure-of-arrays. ==== */

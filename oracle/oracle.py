@@ -207,3 +207,37 @@ def p3p_ransac(xy, X, K, num_hyp=2000, max_reproj=2.0, confidence=0.0, seed=4095
     if want_all:
         out.update(counts=cnt, costs=cost, poses=poses)
     return out
+
+
+def philox_sample8(seed, hyp, m):
+    idx = np.zeros(8, np.int32)
+    lib().vo_or_philox_sample8(C.c_uint64(seed), C.c_uint32(hyp), C.c_uint32(m), _p(idx))
+    return idx
+
+
+def eight_point(x0, x1):
+    """x0, x1: 8 x 2 K^-1-normalised points -> (ok, E) with x1' E x0 = 0, singular values (1, 1, 0)."""
+    x0 = _c(x0, np.float64).reshape(8, 2); x1 = _c(x1, np.float64).reshape(8, 2)
+    a0 = np.ascontiguousarray(x0[:, 0]); b0 = np.ascontiguousarray(x0[:, 1])
+    a1 = np.ascontiguousarray(x1[:, 0]); b1 = np.ascontiguousarray(x1[:, 1])
+    E = np.zeros((3, 3))
+    ok = lib().vo_or_eight_point(_p(a0), _p(b0), _p(a1), _p(b1), _p(E))
+    return bool(ok), E
+
+
+def essential_ransac(p0, p1, K, num_hyp=2000, max_distance=0.09, confidence=0.995, seed=1023, min_inliers=8,
+                     sample_idx=None, threads=1, want_all=False):
+    """modules/bootstrap.m:76-79 (N10, oracle/essential.c)."""
+    p0 = _c(p0, np.float64).reshape(-1, 2); p1 = _c(p1, np.float64).reshape(-1, 2); K = _c(K, np.float64)
+    m = p0.shape[0]
+    o = RansacOpts(num_hyp, max_distance, confidence, seed, 1, min_inliers, threads)
+    E = np.zeros((3, 3)); inl = np.zeros(max(m, 1), np.uint8)
+    bh = C.c_int(); used = C.c_int()
+    si = None if sample_idx is None else _c(sample_idx, np.int32)
+    cnt = np.zeros(num_hyp, np.int32); cost = np.zeros(num_hyp, np.uint64); Es = np.zeros((num_hyp, 3, 3))
+    st = lib().vo_or_essential_ransac(_p(p0), _p(p1), m, _p(K), C.byref(o), None if si is None else _p(si), _p(E), _p(inl),
+                                      C.byref(bh), C.byref(used), _p(cnt), _p(cost), _p(Es))
+    out = dict(status=st, E=E, inliers=inl[:m].astype(bool), best_hyp=bh.value, trials=used.value)
+    if want_all:
+        out.update(counts=cnt, costs=cost, Es=Es)
+    return out

@@ -215,6 +215,12 @@ static void philox4x32_10(uint32_t c[4], const uint32_t key[2]) {
     }
 }
 
+void vo_or_philox_block(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t out[4]) {
+    uint32_t c[4] = {c0, c1, 0, 0}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    philox4x32_10(c, key);
+    memcpy(out, c, sizeof c);
+}
+
 void vo_or_philox_sample3(uint64_t seed, uint32_t hyp, uint32_t m, int32_t* idx) {
     uint32_t c[4] = {hyp, 0, 0, 0}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     philox4x32_10(c, key);

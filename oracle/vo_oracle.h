@@ -158,6 +158,20 @@ int vo_or_p3p_ransac(const double* xy, const double* X, int m, const double* K,
                      uint8_t* inliers, int* best_hyp, int* best_sol, int* trials_used,
                      int32_t* hyp_count, uint64_t* hyp_cost, double* hyp_poses /* H x 4 x 12 */);
 
+/* N10 (essential.c): bootstrap's estimateEssentialMatrix, modules/bootstrap.m:76-79.  Points are
+ * m x 2 pixel coordinates in K's origin; o->max_reproj is MaxDistance (Sampson, pixels^2),
+ * o->min_inliers the least count a winning hypothesis needs.  Status 0 ok / 1 fewer than 8 points /
+ * 2 no hypothesis qualified.  sample_idx optional H x 8.  E satisfies x1' E x0 = 0 on K^-1-normalised
+ * points and has singular values (1, 1, 0). */
+void vo_or_philox_sample8(uint64_t seed, uint32_t hyp, uint32_t m, int32_t* idx8);
+int vo_or_eight_point(const double* x0, const double* y0, const double* x1, const double* y1, double* E);
+int vo_or_essential_project(const double* E0, double* E);
+void vo_or_fundamental_from_essential(const double* E, const double* K, double* F);
+int vo_or_essential_ransac(const double* p0, const double* p1, int m, const double* K,
+                           const vo_or_ransac_opts* o, const int32_t* sample_idx, double* E,
+                           uint8_t* inliers, int* best_hyp, int* trials_used, int32_t* hyp_count,
+                           uint64_t* hyp_cost, double* hyp_E /* H x 9 */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,9 @@ struct vo_ransac_work { double* Rt; int32_t* cnt; unsigned long long* cost; };
 int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int M,
                      const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
                      const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers);
+int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_strides sp, int M, const double* d_K,
+                        const vo_ransac_opts* o, const int32_t* d_sample_idx, const double* d_E_in, vo_ransac_work* w,
+                        void* d_out, uint8_t* d_inliers);
 int vo_launch_p3p_batch(vo_ctx* ctx, const double* d_P, const double* d_f, int n, double* d_poses);
 
 // ---- helpers of vo_api.hip shared with vo_frame.hip ----

@@ -379,16 +379,20 @@ __device__ __forceinline__ void hyp_best(const int32_t* cnt, const unsigned long
         if (mode == 0 ? (cnt[4 * h + s] > cnt[4 * h + s_best]) : (cost[4 * h + s] < cost[4 * h + s_best])) s_best = s;
     c = cnt[4 * h + s_best]; q = cost[4 * h + s_best];
 }
-__device__ __forceinline__ double ransac_limit(double confidence, int bcnt, int m, int H) {
+__device__ __forceinline__ double ransac_limit(double confidence, int bcnt, int m, int sample_size) {
     double orat = 1.0 - (double)bcnt / (double)m;
     if (orat > 0.9) orat = 0.9;
     double wi = 1.0 - orat;
-    return log(1.0 - confidence) / log(1.0 - wi * wi * wi); // old/ransacLocalization.m:121
+    double wk;
+    if (sample_size == 8) { const double w2 = wi * wi, w4 = w2 * w2; wk = w4 * w4; } // essential.c
+    else wk = wi * wi * wi;                                                            // old/ransacLocalization.m:121
+    return log(1.0 - confidence) / log(1.0 - wk);
 }
 
 struct BestArgs {
     const int32_t* cnt; const unsigned long long* cost; const double* Rt; int H, M, mode, min_inl;
     double confidence; double* out; // R_cw(9) t_cw(3) then 5 int32
+    int sample_size;                // 3 (P3P) or 8 (eight-point)
 };
 
 __device__ __forceinline__ BState combine(int mode, int min_inl, const BState& earlier, const BState& later) {
@@ -437,13 +441,13 @@ __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
     BState cur = carry;
     int stop = 0x7fffffff;
     if (a.confidence > 0) {
-        double N = ransac_limit(a.confidence, cur.c, a.M, a.H);
+        double N = ransac_limit(a.confidence, cur.c, a.M, a.sample_size);
         for (int h = lo; h < hi; ++h) {
             int s, c; unsigned long long q;
             hyp_best(a.cnt, a.cost, a.mode, h, s, c, q);
             if (improves(a.mode, a.min_inl, c, q, cur)) {
                 cur.h = h; cur.s = s; cur.c = c; cur.q = q;
-                N = ransac_limit(a.confidence, cur.c, a.M, a.H);
+                N = ransac_limit(a.confidence, cur.c, a.M, a.sample_size);
             }
             if (!(N > (double)(h + 2))) { stop = h; break; } // :44 `while num_iterations > i`
         }
@@ -526,12 +530,268 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
     hipLaunchKernelGGL(k_score, dim3((H + SC_HB - 1) / SC_HB), dim3(256), 0, ctx->stream, s);
     BestArgs b;
     b.cnt = w->cnt; b.cost = w->cost; b.Rt = Rt; b.H = H; b.M = M; b.mode = o->mode; b.min_inl = o->min_inliers;
-    b.confidence = o->confidence; b.out = (double*)d_out;
+    b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 3;
     hipLaunchKernelGGL(k_best, dim3(1), dim3(BEST_NT), 0, ctx->stream, b);
     InlArgs in;
     in.xy = d_xy; in.sxy = sxy; in.X = d_X; in.sX = sX; in.M = M; in.K = d_K; in.thr2 = thr2; in.out = (double*)d_out;
     in.inliers = d_inliers;
     hipLaunchKernelGGL(k_inliers, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, in);
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}
+
+
+// ================= essential-matrix MSAC (bootstrap, modules/bootstrap.m:76-79; oracle N10) =================
+namespace {
+
+// 8 distinct indices: index j is the (r_j mod (m - j))-th point not drawn before (essential.c)
+__device__ void philox_sample8(uint64_t seed, uint32_t hyp, uint32_t m, int32_t* idx) {
+    uint32_t r[8];
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int b = 0; b < 2; ++b) {
+        uint32_t c[4] = {hyp, (uint32_t)b, 0, 0};
+        philox4x32_10(c, key);
+        for (int k = 0; k < 4; ++k) r[4 * b + k] = c[k];
+    }
+    uint32_t sorted[8];
+    for (int j = 0; j < 8; ++j) {
+        uint32_t v = r[j] % (m - (uint32_t)j);
+        for (int k = 0; k < j; ++k)
+            if (v >= sorted[k]) ++v;
+        int pos = j;
+        while (pos > 0 && sorted[pos - 1] > v) { sorted[pos] = sorted[pos - 1]; --pos; }
+        sorted[pos] = v;
+        idx[j] = (int32_t)v;
+    }
+}
+
+// one-sided Jacobi on the columns of the m x n row-major A (A V = U S), fixed sweeps and pair order
+__device__ void hestenes(double* A, int m, int n, double* V, int sweeps) {
+    for (int i = 0; i < n * n; ++i) V[i] = 0.0;
+    for (int i = 0; i < n; ++i) V[i * n + i] = 1.0;
+    for (int s = 0; s < sweeps; ++s)
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int k = 0; k < m; ++k) {
+                    alpha += A[k * n + p] * A[k * n + p];
+                    beta += A[k * n + q] * A[k * n + q];
+                    gamma += A[k * n + p] * A[k * n + q];
+                }
+                if (gamma == 0.0) continue;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int k = 0; k < m; ++k) {
+                    const double ap = A[k * n + p], aq = A[k * n + q];
+                    A[k * n + p] = c * ap - sn * aq; A[k * n + q] = sn * ap + c * aq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vp = V[k * n + p], vq = V[k * n + q];
+                    V[k * n + p] = c * vp - sn * vq; V[k * n + q] = sn * vp + c * vq;
+                }
+            }
+}
+__device__ double colnorm2(const double* A, int m, int n, int j) {
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += A[k * n + j] * A[k * n + j];
+    return s;
+}
+__device__ void hartley8(const double* x, const double* y, double* xn, double* yn, double* T) {
+    double cx = 0, cy = 0;
+    for (int i = 0; i < 8; ++i) { cx += x[i]; cy += y[i]; }
+    cx /= 8.0; cy /= 8.0;
+    double d = 0;
+    for (int i = 0; i < 8; ++i) { const double dx = x[i] - cx, dy = y[i] - cy; d += sqrt(dx * dx + dy * dy); }
+    d /= 8.0;
+    const double s = 1.4142135623730951 / d;
+    for (int i = 0; i < 8; ++i) { xn[i] = (x[i] - cx) * s; yn[i] = (y[i] - cy) * s; }
+    T[0] = s; T[1] = 0; T[2] = -(s * cx); T[3] = 0; T[4] = s; T[5] = -(s * cy); T[6] = 0; T[7] = 0; T[8] = 1;
+}
+__device__ void mat3(const double* A, const double* B, double* C) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[r * 3 + c] = (A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c]) + A[r * 3 + 2] * B[6 + c];
+}
+__device__ void mat3_tn(const double* A, const double* B, double* C) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[r * 3 + c] = (A[r] * B[c] + A[3 + r] * B[3 + c]) + A[6 + r] * B[6 + c];
+}
+__device__ int essential_project(const double* E0, double* E) {
+    double A[9], V[9];
+    for (int k = 0; k < 9; ++k) A[k] = E0[k];
+    hestenes(A, 3, 3, V, 16);
+    const double nn[3] = {colnorm2(A, 3, 3, 0), colnorm2(A, 3, 3, 1), colnorm2(A, 3, 3, 2)};
+    int a = 0;
+    if (nn[1] > nn[a]) a = 1;
+    if (nn[2] > nn[a]) a = 2;
+    int b = a == 0 ? 1 : 0;
+    for (int j = 0; j < 3; ++j) if (j != a && nn[j] > nn[b]) b = j;
+    if (!(nn[b] > 0.0)) { for (int k = 0; k < 9; ++k) E[k] = 0.0; return 0; }
+    const double sa = sqrt(nn[a]), sb = sqrt(nn[b]);
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k)
+            E[r * 3 + k] = (A[r * 3 + a] / sa) * V[k * 3 + a] + (A[r * 3 + b] / sb) * V[k * 3 + b];
+    return 1;
+}
+__device__ int eight_point(const double* x0, const double* y0, const double* x1, const double* y1, double* E) {
+    double a0[8], b0[8], a1[8], b1[8], T0[9], T1[9], A[72], V[81];
+    hartley8(x0, y0, a0, b0, T0);
+    hartley8(x1, y1, a1, b1, T1);
+    for (int i = 0; i < 8; ++i) {
+        double* r = A + 9 * i;
+        r[0] = a1[i] * a0[i]; r[1] = a1[i] * b0[i]; r[2] = a1[i];
+        r[3] = b1[i] * a0[i]; r[4] = b1[i] * b0[i]; r[5] = b1[i];
+        r[6] = a0[i]; r[7] = b0[i]; r[8] = 1.0;
+    }
+    hestenes(A, 8, 9, V, 16);
+    int best = 0; double bn = INFINITY;
+    for (int j = 0; j < 9; ++j) { const double n2 = colnorm2(A, 8, 9, j); if (n2 < bn) { bn = n2; best = j; } }
+    double F[9], FT0[9], E0[9];
+    for (int k = 0; k < 9; ++k) F[k] = V[k * 9 + best];
+    mat3(F, T0, FT0);
+    mat3_tn(T1, FT0, E0);
+    bool finite = true;
+    for (int k = 0; k < 9; ++k) if (!(fabs(E0[k]) < INFINITY)) finite = false;
+    if (!finite) { for (int k = 0; k < 9; ++k) E[k] = 0.0; return 0; }
+    return essential_project(E0, E);
+}
+__device__ void fundamental_from_essential(const double* E, const double* K, double* F) {
+    const double fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+    const double Ki[9] = {1.0 / fx, -sk / (fx * fy), (sk * cy - cx * fy) / (fx * fy), 0, 1.0 / fy, -cy / fy, 0, 0, 1};
+    double EK[9];
+    mat3(E, Ki, EK);
+    mat3_tn(Ki, EK, F);
+}
+__device__ __forceinline__ double sampson(const double* F, double u0, double v0, double u1, double v1) {
+    const double a0 = (F[0] * u0 + F[1] * v0) + F[2], a1 = (F[3] * u0 + F[4] * v0) + F[5], a2 = (F[6] * u0 + F[7] * v0) + F[8];
+    const double b0 = (F[0] * u1 + F[3] * v1) + F[6], b1 = (F[1] * u1 + F[4] * v1) + F[7];
+    const double num = (u1 * a0 + v1 * a1) + a2;
+    const double den = (a0 * a0 + a1 * a1) + (b0 * b0 + b1 * b1);
+    return (num * num) / den;
+}
+
+struct EHypArgs {
+    const double *p0, *p1; vo_strides sp; int M; const double* K; int H; uint64_t seed; const int32_t* sample_idx;
+    double* E48;   // hypothesis h at E48 + 48 h (9 doubles; the stride matches the pose table k_best reads)
+};
+__global__ __launch_bounds__(64) void k_e_hyp(EHypArgs a) {
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.H) return;
+    int32_t id[8];
+    bool ok = true;
+    if (a.sample_idx) {
+        for (int k = 0; k < 8; ++k) { id[k] = a.sample_idx[8 * h + k]; if (id[k] < 0 || id[k] >= a.M) ok = false; }
+    } else philox_sample8(a.seed, (uint32_t)h, (uint32_t)a.M, id);
+    double E[9];
+    for (int k = 0; k < 9; ++k) E[k] = 0.0;
+    if (ok) {
+        const double fx = a.K[0], sk = a.K[1], cx = a.K[2], fy = a.K[4], cy = a.K[5];
+        double x0[8], y0[8], x1[8], y1[8];
+        for (int k = 0; k < 8; ++k) {
+            const long i = id[k];
+            const double u0 = a.p0[i * a.sp.xi], v0 = a.p0[i * a.sp.xi + a.sp.xc];
+            const double u1 = a.p1[i * a.sp.xi], v1 = a.p1[i * a.sp.xi + a.sp.xc];
+            y0[k] = (v0 - cy) / fy; x0[k] = ((u0 - cx) - sk * y0[k]) / fx;
+            y1[k] = (v1 - cy) / fy; x1[k] = ((u1 - cx) - sk * y1[k]) / fx;
+        }
+        eight_point(x0, y0, x1, y1, E);
+    }
+    double* o = a.E48 + 48 * (long)h;
+    for (int k = 0; k < 9; ++k) o[k] = E[k];
+    for (int k = 9; k < 48; ++k) o[k] = 0.0;
+}
+
+struct EScoreArgs {
+    const double *p0, *p1; vo_strides sp; int M; const double* K; int H; double thr; const double* E; int e_stride;
+    int32_t* cnt; unsigned long long* cost; // H x 4: solution 0 carries the hypothesis, 1..3 are disabled
+};
+// one 256-thread block per hypothesis
+__global__ __launch_bounds__(256) void k_e_score(EScoreArgs a) {
+    __shared__ double sF[9];
+    __shared__ int s_ok;
+    __shared__ int s_cnt[4];
+    __shared__ unsigned long long s_cost[4];
+    const int h = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        const double* E = a.E + (long)a.e_stride * h;
+        double e[9], F[9];
+        bool nz = false;
+        for (int k = 0; k < 9; ++k) { e[k] = E[k]; if (e[k] != 0.0) nz = true; }
+        fundamental_from_essential(e, a.K, F);
+        for (int k = 0; k < 9; ++k) sF[k] = F[k];
+        s_ok = nz ? 1 : 0;
+    }
+    __syncthreads();
+    const unsigned long long qthr = (unsigned long long)(a.thr * 1048576.0);
+    int c = 0; unsigned long long q = 0;
+    if (s_ok) {
+        double F[9];
+        for (int k = 0; k < 9; ++k) F[k] = sF[k];
+        for (int i = tid; i < a.M; i += 256) {
+            const double d = sampson(F, a.p0[i * a.sp.xi], a.p0[i * a.sp.xi + a.sp.xc], a.p1[i * a.sp.xi], a.p1[i * a.sp.xi + a.sp.xc]);
+            if (d < a.thr) { ++c; q += (unsigned long long)(d * 1048576.0); } else q += qthr;
+        }
+    } else {
+        for (int i = tid; i < a.M; i += 256) q += qthr;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { c += __shfl_xor(c, d, 64); q += __shfl_xor(q, d, 64); }
+    if ((tid & 63) == 0) { s_cnt[tid >> 6] = c; s_cost[tid >> 6] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        a.cnt[4 * (long)h] = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+        a.cost[4 * (long)h] = (s_cost[0] + s_cost[1]) + (s_cost[2] + s_cost[3]);
+        for (int s = 1; s < 4; ++s) { a.cnt[4 * (long)h + s] = 0; a.cost[4 * (long)h + s] = ~0ull; }
+    }
+}
+
+struct EInlArgs { const double *p0, *p1; vo_strides sp; int M; const double* K; double thr; double* out; uint8_t* inliers; };
+__global__ __launch_bounds__(256) void k_e_inliers(EInlArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int32_t* info = (int32_t*)(a.out + 12);
+    bool in = false;
+    if (i < a.M && info[0] == 0) {
+        double F[9];
+        fundamental_from_essential(a.out, a.K, F);
+        in = sampson(F, a.p0[i * a.sp.xi], a.p0[i * a.sp.xi + a.sp.xc], a.p1[i * a.sp.xi], a.p1[i * a.sp.xi + a.sp.xc]) < a.thr;
+    }
+    if (i < a.M) a.inliers[i] = in ? 1 : 0;
+    const unsigned long long bal = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&info[4], (int)__popcll(bal));
+}
+
+} // namespace
+
+// d_out: E (9 doubles, 3 of padding) followed by vo_ransac_info as 5 int32; w as for the pose step.
+// d_E_in (optional): H x 9 hypotheses to score instead of sampling ("identical hypotheses").
+int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_strides sp, int M, const double* d_K,
+                        const vo_ransac_opts* o, const int32_t* d_sample_idx, const double* d_E_in, vo_ransac_work* w,
+                        void* d_out, uint8_t* d_inliers) {
+    const int H = o->num_hyp;
+    if (H < 1 || M < 8 || !(o->max_reproj_err > 0)) { ctx->last_error = "essential: need num_hyp >= 1, M >= 8, MaxDistance > 0"; return VO_ERR_BAD_ARG; }
+    const double* E = w->Rt; int e_stride = 48;
+    if (d_E_in) { E = d_E_in; e_stride = 9; }
+    else {
+        EHypArgs h;
+        h.p0 = d_p0; h.p1 = d_p1; h.sp = sp; h.M = M; h.K = d_K; h.H = H; h.seed = o->seed; h.sample_idx = d_sample_idx; h.E48 = w->Rt;
+        hipLaunchKernelGGL(k_e_hyp, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, h);
+    }
+    EScoreArgs s;
+    s.p0 = d_p0; s.p1 = d_p1; s.sp = sp; s.M = M; s.K = d_K; s.H = H; s.thr = o->max_reproj_err; s.E = E; s.e_stride = e_stride;
+    s.cnt = w->cnt; s.cost = w->cost;
+    hipLaunchKernelGGL(k_e_score, dim3(H), dim3(256), 0, ctx->stream, s);
+    if (d_E_in) { // k_best copies the winner out of a stride-48 table
+        VO_HIP_CHECK(ctx, hipMemsetAsync(w->Rt, 0, sizeof(double) * 48 * (size_t)H, ctx->stream));
+        VO_HIP_CHECK(ctx, hipMemcpy2DAsync(w->Rt, 48 * sizeof(double), d_E_in, 9 * sizeof(double), 9 * sizeof(double), H,
+                                           hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    BestArgs b;
+    b.cnt = w->cnt; b.cost = w->cost; b.Rt = w->Rt; b.H = H; b.M = M; b.mode = 1; b.min_inl = o->min_inliers;
+    b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 8;
+    hipLaunchKernelGGL(k_best, dim3(1), dim3(BEST_NT), 0, ctx->stream, b);
+    EInlArgs in;
+    in.p0 = d_p0; in.p1 = d_p1; in.sp = sp; in.M = M; in.K = d_K; in.thr = o->max_reproj_err; in.out = (double*)d_out; in.inliers = d_inliers;
+    hipLaunchKernelGGL(k_e_inliers, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, in);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }
