@@ -1,0 +1,107 @@
+"""Bootstrap (modules/bootstrap.m) through the C ABI against the oracle: the
+essential-matrix MSAC bit for bit under identical hypotheses and on the seeded stream, the whole
+bootstrap on a non-planar synthetic pair, and the hand-over into the device-resident frame loop."""
+import numpy as np
+import pytest
+
+from oracle import bootstrap as obootstrap
+from oracle import oracle
+from visual_odometry_amd import modules, ops, synth
+from visual_odometry_amd.frame import FrameLoop
+
+pytestmark = pytest.mark.gpu
+K = np.array([[300.0, 0, 160.0], [0, 300.0, 120.0], [0, 0, 1.0]])
+
+
+def two_view_points(n=2500, seed=3, outliers=0.2, noise=0.05):
+    rng = np.random.default_rng(seed)
+    X = np.stack([rng.uniform(-20, 20, n), rng.uniform(-5, 5, n), rng.uniform(8, 60, n)], 1)
+    R, C = synth.rot_y(2.0), np.array([0.8, 0.05, 0.3])
+    p0, _ = synth.project(synth.KITTI_K, np.eye(3), np.zeros(3), X)
+    p1, _ = synth.project(synth.KITTI_K, R, C, X)
+    p0 = p0 + rng.normal(0, noise, p0.shape); p1 = p1 + rng.normal(0, noise, p1.shape)
+    out = rng.random(n) < outliers
+    p1[out] += rng.uniform(-30, 30, (int(out.sum()), 2))
+    return p0, p1, out, R, C
+
+
+@pytest.mark.parametrize("confidence", [0.0, 0.995])
+def test_essential_identical_hypotheses_bit_exact(ctx, confidence):
+    p0, p1, out, R, C = two_view_points()
+    o = oracle.essential_ransac(p0, p1, synth.KITTI_K, num_hyp=600, confidence=confidence, threads=8, want_all=True)
+    g = ops.essential_ransac(p0, p1, synth.KITTI_K, num_hyp=600, confidence=confidence, hyp_E=o["Es"], want_all=True)
+    assert g["status"] == o["status"] == 0 and g["best_hyp"] == o["best_hyp"] and g["trials"] == o["trials"]
+    np.testing.assert_array_equal(g["counts"], o["counts"])
+    np.testing.assert_array_equal(g["costs"], o["costs"])
+    np.testing.assert_array_equal(g["inliers"], o["inliers"])
+    np.testing.assert_array_equal(g["E"], o["E"])
+    assert g["num_inliers"] == o["inliers"].sum() and (o["inliers"] & out).mean() < 0.01
+
+
+def test_essential_seeded_stream_and_sample_table(ctx):
+    """The eight-point hypotheses use sqrt and division only (no libm), so even they agree bit for bit."""
+    p0, p1, out, R, C = two_view_points(n=1200, seed=4)
+    o = oracle.essential_ransac(p0, p1, synth.KITTI_K, num_hyp=500, seed=77, threads=8, want_all=True)
+    g = ops.essential_ransac(p0, p1, synth.KITTI_K, num_hyp=500, seed=77, want_all=True)
+    assert (g["Es"] == o["Es"]).all(axis=(1, 2)).mean() > 0.99 and np.abs(g["Es"] - o["Es"]).max() < 1e-9
+    same = (g["Es"] == o["Es"]).all(axis=(1, 2))
+    np.testing.assert_array_equal(g["counts"][same], o["counts"][same])
+    np.testing.assert_array_equal(g["costs"][same], o["costs"][same])
+    idx = np.stack([oracle.philox_sample8(77, h, len(p0)) for h in range(500)])
+    assert all(len(set(r)) == 8 for r in idx)
+    g2 = ops.essential_ransac(p0, p1, synth.KITTI_K, num_hyp=500, sample_idx=idx, want_all=True)
+    np.testing.assert_array_equal(g2["Es"], g["Es"])
+    # the recovered E is the true one up to sign (minimal samples on noisy points: loose bound)
+    t = -R @ C
+    Et = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+    Et *= np.sqrt(2) / np.linalg.norm(Et)
+    assert min(np.abs(g["E"] - Et).max(), np.abs(g["E"] + Et).max()) < 0.2
+    np.testing.assert_allclose(np.linalg.svd(g["E"])[1], [1, 1, 0], atol=1e-12)
+
+
+def test_essential_statuses(ctx):
+    p0, p1, *_ = two_view_points(n=40, outliers=0.0)
+    r = ops.essential_ransac(p0[:7], p1[:7], synth.KITTI_K, num_hyp=10)
+    assert r["status"] == 1 and not r["inliers"].any() and not r["E"].any()           # fewer than 8 correspondences
+    junk = np.random.default_rng(0).uniform(0, 300, (40, 2))
+    r = ops.essential_ransac(p0, junk, synth.KITTI_K, num_hyp=50, min_inliers=30)
+    o = oracle.essential_ransac(p0, junk, synth.KITTI_K, num_hyp=50, min_inliers=30)
+    assert r["status"] == o["status"] == 2
+    E, inl, status = modules.estimateEssentialMatrix(p0, p1, modules.CameraParams(synth.KITTI_K), MaxNumTrials=200,
+                                                     Confidence=99.5, MaxDistance=0.09)
+    assert status == 0 and inl.mean() > 0.6
+
+
+def test_bootstrap_matches_the_oracle_and_feeds_the_frame_loop(ctx):
+    frames, poses, lift = synth.relief_sequence(7, K)
+    kp_o, X_o, rep_o, pose_o, info_o = obootstrap.bootstrap(frames[0], frames[2], K, threads=8)
+    K1 = K.copy(); K1[0, 2] += 1; K1[1, 2] += 1                       # MATLAB: 1-based pixels, K in the same origin
+    kp, X, rep, pose, info = modules.bootstrap(frames[0], frames[2], modules.CameraParams(K1), return_info=True)
+    got = (info["corners"], info["tracked"], info["inliers"], info["attempts"])
+    assert got == (info_o["corners"], info_o["tracked"], info_o["inliers"], info_o["attempts"])
+    assert len(kp) == len(kp_o) > 500
+    assert np.abs(kp - 1 - kp_o).max() < 0.01
+    np.testing.assert_allclose(pose, pose_o, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(X, X_o, rtol=2e-3, atol=2e-3)
+    assert np.abs(rep - rep_o).max() < 0.01
+    # up to the unknown scale the pose is the true one (minimal-sample E: loose bounds)
+    Ct = poses[2][3]
+    assert np.abs(pose[:3] - poses[2][:3]).max() < 0.02 and np.abs(pose[3] - Ct / np.linalg.norm(Ct)).max() < 0.15
+    # hand-over: zero-based state into the device-resident loop, frames 3..6
+    st = modules._new_state()
+    st.keypoints = kp - 1; st.landmarks = X; st.reproError = rep
+    st.candidate_first_poses = np.zeros((0, 4, 3))
+    loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=400, ctx=ctx)
+    sel = np.argsort(rep)[:400]
+    st.keypoints, st.landmarks, st.reproError = st.keypoints[sel], st.landmarks[sel], st.reproError[sel]
+    loop.set_state(st, frames[2])
+    scale = 1.0 / np.linalg.norm(Ct)
+    for k in range(3, 7):
+        p, status, finfo = loop.processFrame(frames[k])
+        assert status == 0 and finfo["n_landmarks"] > 150
+        # minimal-sample bootstrap + minimal-sample poses drift: direction and magnitude, loosely
+        c_est, c_true = p[3], poses[k][3] * scale
+        cosang = c_est @ c_true / (np.linalg.norm(c_est) * np.linalg.norm(c_true))
+        assert cosang > 0.9 and 0.5 < np.linalg.norm(c_est) / np.linalg.norm(c_true) < 2.0
+        assert np.abs(p[:3] - poses[k][:3]).max() < 0.08
+    loop.close()

@@ -307,3 +307,43 @@ def test_frame_step_restatement_runs_a_sequence():
         assert np.abs(pose[3] - poses[k][3]).max() < 0.3 and np.abs(pose[:3] - poses[k][:3]).max() < 0.05
         promoted += info["promoted"]
     assert promoted > 0 and st.candidate_time_indxs.min() < -1 and (st.reproError < 3.0).all()
+
+
+def test_eight_point_and_essential_msac():
+    """N10 (oracle/essential.c): exact correspondences give the true E up to sign; the MSAC separates
+    gross outliers; samples are 8 distinct indices."""
+    rng = np.random.default_rng(2)
+    n = 600
+    X = np.stack([rng.uniform(-20, 20, n), rng.uniform(-5, 5, n), rng.uniform(8, 60, n)], 1)
+    R, C = synth.rot_y(3.0), np.array([1.0, -0.1, 0.2])
+    K = synth.KITTI_K
+    p0, _ = synth.project(K, np.eye(3), np.zeros(3), X)
+    p1, _ = synth.project(K, R, C, X)
+    t = -R @ C
+    Et = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+    Et *= np.sqrt(2) / np.linalg.norm(Et)
+    Ki = np.linalg.inv(K)
+    x0 = (np.c_[p0[:8], np.ones(8)] @ Ki.T)[:, :2]; x1 = (np.c_[p1[:8], np.ones(8)] @ Ki.T)[:, :2]
+    ok, E = oracle.eight_point(x0, x1)
+    assert ok and min(np.abs(E - Et).max(), np.abs(E + Et).max()) < 1e-8
+    np.testing.assert_allclose(np.linalg.svd(E)[1], [1, 1, 0], atol=1e-12)
+    out = rng.random(n) < 0.25
+    p1n = p1 + rng.normal(0, 0.03, p1.shape)
+    p1n[out] += rng.uniform(-40, 40, (int(out.sum()), 2))
+    r = oracle.essential_ransac(p0, p1n, K, num_hyp=500, threads=8)
+    assert r["status"] == 0 and (r["inliers"] & out).sum() <= 2 and r["inliers"][~out].mean() > 0.6
+    assert oracle.essential_ransac(p0[:7], p1[:7], K)["status"] == 1
+    for h in range(50):
+        s = oracle.philox_sample8(9, h, 11)
+        assert len(set(s)) == 8 and s.min() >= 0 and s.max() < 11
+
+
+def test_bootstrap_restatement_on_a_relief_scene():
+    from oracle import bootstrap as ob
+    K = np.array([[300.0, 0, 160.0], [0, 300.0, 120.0], [0, 0, 1.0]])
+    frames, poses, lift = synth.relief_sequence(3, K)
+    kp, X, rep, pose, info = ob.bootstrap(frames[0], frames[2], K, threads=8)
+    Ct = poses[2][3]
+    assert len(kp) == len(X) == len(rep) > 500 and info["attempts"] == 1
+    assert np.abs(pose[:3] - poses[2][:3]).max() < 0.02 and np.abs(pose[3] - Ct / np.linalg.norm(Ct)).max() < 0.15
+    assert np.median(rep) < 0.2 and (X[:, 2] > 0).all()

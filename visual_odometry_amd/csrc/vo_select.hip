@@ -328,7 +328,10 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
     const float inv_nu = 1.0f / (float)a.nu, inv_nv = 1.0f / (float)a.nv;
     // A round has at most `want` <= n_keep cells.  When the cell tables fit LDS and a thread's share
     // of the kept corners fits its registers, the rounds touch neither L2 nor HBM.
-    const bool fast = nl <= 1024 * UNI_KPT && a.n_keep <= UNI_LDS_CELLS - 1 && m <= 0x1ffff;
+    // asking for at least as many points as survive selects them all (bootstrap: selectUniform over every
+    // detected corner, modules/bootstrap.m:36-38) -- the rounds would end there too
+    const bool all = a.n_keep >= nl;
+    const bool fast = !all && nl <= 1024 * UNI_KPT && a.n_keep <= UNI_LDS_CELLS - 1 && m <= 0x1ffff;
     if (fast) {
         // per corner: coordinates, metric key, and one packed word: index (bits 0-16, corners < 2^17 by
         // the capacity rule n/4+16 is checked on the host), this round's cell (17-27), selected (31)
@@ -407,10 +410,10 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
         if (t == 0) *a.out_count = S;
         return;
     }
-    for (int i = t; i < m; i += 1024) a.sel[i] = 0;
+    for (int i = t; i < m; i += 1024) a.sel[i] = all ? a.keep[i] : 0;
     __threadfence_block();
     __syncthreads();
-    while (true) {
+    while (!all) {
         const int selected = s_selected, remaining = s_remaining;
         if (!(selected < a.n_keep && remaining > 0)) break;
         const long want = a.n_keep - selected;

@@ -16,6 +16,7 @@ N x 2 `[x y]` with 1-based pixel coordinates, poses are 4 x 3 `[R_WC; t_WC]`
     calculateAngleDeg           utils/calculateAngleDeg.m:1-11
     isInFrontOfCamera           modules/isInFrontOfCamera.m:1-12
     harris, selectKeypoints, p3p  old/harris.m, old/selectKeypoints.m, old/p3p.m
+    bootstrap, estimateEssentialMatrix, relativeCameraPose   modules/bootstrap.m:1-135 and its toolbox calls
 """
 from types import SimpleNamespace
 
@@ -238,3 +239,85 @@ class VisualOdometry:
         cs.candidate_first_poses = list(cs.candidate_first_poses) + [curr_pose] * len(new)
         cs.candidate_time_indxs = np.concatenate([cs.candidate_time_indxs, -np.ones(len(new), np.int64)])
         return cs, curr_pose, status
+
+
+# ---------------------------------------------------------------- bootstrap (modules/bootstrap.m)
+def estimateEssentialMatrix(matchedPoints1, matchedPoints2, cameraParams, MaxNumTrials=500, Confidence=99,
+                            MaxDistance=0.1, Seed=1023):
+    """[E, inliersIndex, status] of the toolbox call at modules/bootstrap.m:76-79: MSAC around the
+    normalised eight-point algorithm (definition N10).  E satisfies x2' E x1 = 0 on normalised points."""
+    K = cameraParams.K if hasattr(cameraParams, "K") else np.asarray(cameraParams.IntrinsicMatrix).T
+    r = ops.essential_ransac(matchedPoints1, matchedPoints2, K, num_hyp=MaxNumTrials, max_distance=MaxDistance,
+                             confidence=Confidence / 100.0, seed=Seed, min_inliers=8)
+    return r["E"], r["inliers"], r["status"]
+
+
+def _decompose_essential(E):
+    U, _, Vt = np.linalg.svd(E)
+    if np.linalg.det(U) < 0:
+        U = -U
+    if np.linalg.det(Vt) < 0:
+        Vt = -Vt
+    W = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    Ra, Rb, t = U @ W @ Vt, U @ W.T @ Vt, U[:, 2]
+    return [(Ra, t), (Ra, -t), (Rb, t), (Rb, -t)]
+
+
+def relativeCameraPose(E, cameraParams, inlierPoints1, inlierPoints2):
+    """[orientation, location, validPointsFraction] (modules/bootstrap.m:93-94): of the four
+    decompositions of E the one with most points in front of both cameras (batched GPU triangulation)."""
+    K = cameraParams.K if hasattr(cameraParams, "K") else np.asarray(cameraParams.IntrinsicMatrix).T
+    p0 = np.asarray(inlierPoints1, np.float64); p1 = np.asarray(inlierPoints2, np.float64)
+    n = len(p0)
+    pose0 = np.vstack([np.eye(3), np.zeros((1, 3))])
+    best = None
+    for R, t in _decompose_essential(np.asarray(E, np.float64)):
+        pose1 = np.vstack([R, (-(R.T @ t)).reshape(1, 3)])
+        _, _, _, ok = ops.triangulate_candidates(p0, p1, pose0[None], pose1, K, first_pose_idx=np.ones(n, np.int32))
+        c = int(ok.sum())
+        if best is None or c > best[0]:
+            best = (c, pose1)
+    return best[1][:3], best[1][3].reshape(1, 3), best[0] / max(n, 1)
+
+
+def bootstrap(img0, img1, cameraParams, PlotResult=False, MinDepth=0.0, MaxDepth=5000.0, MinNumLandmarks=50,
+              FeatureMatchingMode="KLT", MinQuality=0.01, FilterSize=5, uniformFeaturesPercentage=100.0,
+              Seed=1023, MaxAttempts=20, return_info=False):
+    """[keypoints, landmarks, reproError, pose] = bootstrap(img0, img1, cameraParams, ...)
+    (modules/bootstrap.m:1-135).  'HardMatching' (:40-55, descriptor matching) is not built: only the
+    default KLT mode.  The reference loops until enough landmarks exist (:74); here at most MaxAttempts
+    reseeded attempts, then an error."""
+    del PlotResult
+    if FeatureMatchingMode != "KLT":
+        raise NotImplementedError("bootstrap: only FeatureMatchingMode='KLT' is built")
+    K = cameraParams.K if hasattr(cameraParams, "K") else np.asarray(cameraParams.IntrinsicMatrix).T
+    H, W = np.asarray(img0).shape
+    cap = H * W // 4 + 16
+    none = np.zeros((0, 2), np.float32)
+    pts0 = ops.select_candidates(img0, none, min_distance=0.0, min_quality=MinQuality, filter_size=FilterSize, keep=cap)  # :30-32
+    n_keep = int(round(len(pts0) * uniformFeaturesPercentage / 100.0))                                                    # :36-38
+    if n_keep < len(pts0):
+        pts0 = ops.select_candidates(img0, none, min_distance=0.0, min_quality=MinQuality, filter_size=FilterSize, keep=n_keep)
+    points, validity, _ = KLTTracker().track(img0, img1, pts0.astype(np.float64))                                       # :57-58
+    m0 = pts0.astype(np.float64)[validity]; m1 = points[validity]                                                        # :59-60
+    pose0 = np.vstack([np.eye(3), np.zeros((1, 3))])
+    for attempt in range(int(MaxAttempts)):                                                                               # :74
+        r = ops.essential_ransac(m0, m1, K, num_hyp=2000, max_distance=0.09, confidence=0.995, seed=Seed + attempt,
+                                 min_inliers=8)                                                                          # :76-79
+        inl = r["inliers"]
+        if r["status"] != 0 or inl.sum() < MinNumLandmarks:                                                               # :83-86
+            continue
+        a, b = m0[inl], m1[inl]
+        R1, t1, frac = relativeCameraPose(r["E"], cameraParams, a, b)                                                     # :93-94
+        if inl.sum() * frac < MinNumLandmarks or not np.isfinite(R1).all() or not np.isfinite(t1).all():                  # :97-100
+            continue
+        pose = np.vstack([R1, t1])
+        X, rep, _, ok = ops.triangulate_candidates(a, b, pose0[None], pose, K, first_pose_idx=np.ones(len(a), np.int32))  # :120-121
+        ok = ok & (X[:, 2] > MinDepth) & (X[:, 2] <= MaxDepth)                                                            # :124-125
+        if ok.sum() >= MinNumLandmarks:                                                                                   # :128
+            out = (b[ok], X[ok], rep[ok], pose)                                                                           # :132-135
+            if return_info:
+                return out + (dict(corners=len(pts0), tracked=int(validity.sum()), inliers=int(inl.sum()),
+                                   attempts=attempt + 1, valid_fraction=frac, trials=r["trials"]),)
+            return out
+    raise RuntimeError("bootstrap: no attempt produced enough landmarks")

@@ -172,3 +172,42 @@ def plane_sequence(n_frames, K, nv=240, nu=320, seed=77, depth=12.0, step=(0.12,
         return np.stack([(u - K[0, 2]) / K[0, 0] * depth, (v - K[1, 2]) / K[1, 1] * depth, np.full_like(u, depth, dtype=np.float64)], 1)
 
     return frames, poses, lift
+
+
+def relief_sequence(n_frames, K, nv=240, nu=320, seed=91, depth=12.0, relief=2.5, step=(0.25, 0.03, 0.05), yaw_deg=0.2,
+                    noise=0.5):
+    """A non-planar 3D-consistent sequence (the bootstrap's eight-point solver is degenerate on a
+    plane): a textured height field Z(u0, v0) = depth + relief * smooth noise over the image plane of
+    view 0 (frame 0 = the texture), seen by a camera that moves by `step` and turns by `yaw_deg` per
+    frame.  Returns frames, poses (4x3 [R_cw; C]) and lift(u0, v0) -> landmarks."""
+    margin = 96
+    tex = texture(nv, nu, seed, margin=margin)
+    r = _rng(seed + 7)
+    zmap = ndimage.gaussian_filter(r.standard_normal(tex.shape), 28.0)
+    zmap = depth + relief * zmap / np.abs(zmap).max()
+    vv, uu = np.mgrid[0:nv, 0:nu].astype(np.float64)
+    rays = np.linalg.inv(K) @ np.stack([uu.ravel(), vv.ravel(), np.ones(uu.size)], 0)
+    frames, poses = [], []
+    for k in range(n_frames):
+        R_cw = rot_y(yaw_deg * k)
+        C = np.array(step, dtype=np.float64) * k
+        d = R_cw.T @ rays
+        lam = (depth - C[2]) / d[2]
+        for _ in range(12):                                   # ray / height-field intersection, fixed point
+            X = C[:, None] + lam * d
+            u0 = K[0, 0] * X[0] / X[2] + K[0, 2]; v0 = K[1, 1] * X[1] / X[2] + K[1, 2]
+            zs = ndimage.map_coordinates(zmap, [v0 + margin, u0 + margin], order=1, mode="nearest")
+            lam = (zs - C[2]) / d[2]
+        X = C[:, None] + lam * d
+        u0 = K[0, 0] * X[0] / X[2] + K[0, 2]; v0 = K[1, 1] * X[1] / X[2] + K[1, 2]
+        img = ndimage.map_coordinates(tex, [v0.reshape(nv, nu) + margin, u0.reshape(nv, nu) + margin], order=3, mode="nearest")
+        if noise > 0:
+            img = img + r.normal(0, noise, img.shape)
+        frames.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+        poses.append(pose43(R_cw, C))
+
+    def lift(u, v):
+        z = ndimage.map_coordinates(zmap, [np.asarray(v) + margin, np.asarray(u) + margin], order=1, mode="nearest")
+        return np.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z], 1)
+
+    return frames, poses, lift
