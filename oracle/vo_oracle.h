@@ -11,7 +11,7 @@
  * restate OPEN reference code (old/p3p.m, old/solveQuartic.m, old/ransacLocalization.m,
  * old/harris.m, old/selectKeypoints.m, old/linearTriangulation.m, utils/calculateAngleDeg.m,
  * modules/isInFrontOfCamera.m) follow it line by line and cite it; toolbox-internal steps are
- * DEFINED here (normative definitions N1..N9 below) from the public documentation and the
+ * DEFINED here (normative definitions N1..N10 below) from the public documentation and the
  * Bouguet / Shi-Tomasi / Kneip / Torr-Zisserman papers.  The oracle is pinned by analytic
  * known-answer tests (tests/test_oracle_*.py) and by the fixtures under tests/golden/ that it
  * emitted itself (tests/golden/make_golden.py).
@@ -65,6 +65,8 @@
  *                |p - proj|^2 < thr^2, old/ransacLocalization.m:96-99; z = 0 is never an inlier);
  *                MSAC cost = sum over inliers of floor(e2 * 2^20), e2 = ez / z^2, plus
  *                floor(thr^2 * 2^20) per outlier; see p3p.c.
+ * N10 essential   bootstrap's estimateEssentialMatrix: MSAC around the normalised eight-point algorithm,
+ *                Sampson distance in pixels^2, Philox samples of 8; see essential.c.
  */
 #ifndef VO_ORACLE_H
 #define VO_ORACLE_H
