@@ -127,7 +127,12 @@ def main():
     from visual_odometry_amd import _lib, dist
     from visual_odometry_amd.device import FrameWorkload
 
-    rank, local_rank, world = dist.init()
+    # VO_REHEARSE_ONE_GPU=1: every rank on device 0 with gloo for the statistics -- a rehearsal of the
+    # N > 1 code path on a one-GPU box (the numbers mean nothing); never set by the driver
+    rehearse = bool(os.environ.get("VO_REHEARSE_ONE_GPU"))
+    rank, local_rank, world = dist.init("gloo" if rehearse else None)
+    if rehearse:
+        local_rank = 0
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
