@@ -28,7 +28,7 @@ struct RespArgs {
 };
 
 // One block = one RS_TU x RS_TV tile.  LDS: uint8 tile with halo r+1; int32 products on the tile
-// with halo r; int64 horizontal sums.  MINEIGEN uses replicate borders at every stage (N6), HARRIS
+// with halo r; int32 horizontal sums, int64 vertical sums.  MINEIGEN uses replicate borders at every stage (N6), HARRIS
 // only produces values where the whole support is inside the image (old/harris.m 'valid').
 __global__ __launch_bounds__(256) void k_response(RespArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -39,9 +39,11 @@ __global__ __launch_bounds__(256) void k_response(RespArgs a) {
     int32_t* pa = (int32_t*)(smem + ((SW * SH + 15) & ~15));
     int32_t* pb = pa + PW * PH;
     int32_t* pc = pb + PW * PH;
-    long long* ha = (long long*)(pc + PW * PH + ((PW * PH) & 1));
-    long long* hb = ha + RS_TU * PH;
-    long long* hc = hb + RS_TU * PH;
+    // horizontal sums fit int32: |product| <= 255^2 (min-eigen) or (4*255)^2 (Harris), weights sum to
+    // 4096 (Gaussian, N6) or the patch width <= 15 (box); the vertical sums need 64 bits
+    int32_t* ha = pc + PW * PH;
+    int32_t* hb = ha + RS_TU * PH;
+    int32_t* hc = hb + RS_TU * PH;
     const int u0 = blockIdx.x * RS_TU, v0 = blockIdx.y * RS_TV;
     const int su0 = u0 - r - 1, sv0 = v0 - r - 1;
     const int tid = threadIdx.x;
@@ -77,13 +79,13 @@ __global__ __launch_bounds__(256) void k_response(RespArgs a) {
     // horizontal pass.  MINEIGEN: index clamp(u+k) of the product arrays (replicate the PRODUCTS).
     for (int c = tid; c < RS_TU * PH; c += 256) {
         int y = c / RS_TU, x = c - y * RS_TU;
-        long long sa = 0, sb = 0, sc = 0;
+        int32_t sa = 0, sb = 0, sc = 0;
         for (int k = -r; k <= r; ++k) {
             int xx;
             if (a.scorer == VO_SCORER_MINEIGEN) xx = clampi(u0 + x + k, 0, nu - 1) - (u0 - r);
             else xx = x + r + k;
             xx = clampi(xx, 0, PW - 1);
-            long long w = a.w[k + r];
+            const int32_t w = a.w[k + r];
             sa += w * pa[y * PW + xx]; sb += w * pb[y * PW + xx]; sc += w * pc[y * PW + xx];
         }
         ha[c] = sa; hb[c] = sb; hc[c] = sc;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void k_response(RespArgs a) {
             if (a.scorer == VO_SCORER_MINEIGEN) yy = clampi(v + k, 0, nv - 1) - (v0 - r);
             else yy = y + r + k;
             yy = clampi(yy, 0, PH - 1);
-            long long w = a.w[k + r];
+            const long long w = a.w[k + r];
             sa += w * ha[yy * RS_TU + x]; sb += w * hb[yy * RS_TU + x]; sc += w * hc[yy * RS_TU + x];
         }
         double out;
@@ -584,8 +586,7 @@ int vo_launch_response(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int sc
     if (scorer == VO_SCORER_MINEIGEN) gauss_weights_host(fs, a.w);
     const int r = a.r;
     const int SW = RS_TU + 2 * r + 2, SH = RS_TV + 2 * r + 2, PW = RS_TU + 2 * r, PH = RS_TV + 2 * r;
-    size_t lds = ((size_t)(SW * SH + 15) & ~(size_t)15) + sizeof(int32_t) * (3 * (size_t)PW * PH + ((PW * PH) & 1)) +
-                 sizeof(long long) * 3 * (size_t)RS_TU * PH;
+    size_t lds = ((size_t)(SW * SH + 15) & ~(size_t)15) + sizeof(int32_t) * (3 * (size_t)PW * PH + 3 * (size_t)RS_TU * PH);
     if (d_maxbits) VO_HIP_CHECK(ctx, hipMemsetAsync(d_maxbits, 0, sizeof(unsigned long long), ctx->stream));
     dim3 grid((nu + RS_TU - 1) / RS_TU, (nv + RS_TV - 1) / RS_TV);
     static bool attr_set = false;
