@@ -32,6 +32,7 @@
  */
 #ifndef VO_HIP_H
 #define VO_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -46,7 +47,8 @@ enum {
     VO_ERR_BAD_ARG = -2,
     VO_ERR_HIP = -3,
     VO_ERR_OOM = -4,
-    VO_ERR_UNSUPPORTED = -5
+    VO_ERR_UNSUPPORTED = -5,
+    VO_END = 1 /* vo_ingest_next: the sequence is exhausted (not an error) */
 };
 
 typedef struct {
@@ -258,6 +260,45 @@ int vo_frame_set_image(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int 
 /* one processFrame: prev image = the last image given; returns the pose [R_WC; t_WC] and the counts */
 int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device, double pose43[12],
                      vo_frame_info* info);
+
+/* ==== frame ingest: imread + rgb2gray + im2uint8 as the reference's frame loops use
+ * them (main.m:15-30,52-59; utils/dataLoaderKitti.m:29, utils/dataLoaderParking.m:29,
+ * utils/dataLoaderMalaga.m:29-30).  Decoded: PNG (non-interlaced; every colour type and bit depth;
+ * alpha dropped; 16-bit samples reduced as im2uint8 does, round(x / 257); gray below 8 bits scaled to
+ * 0..255; palette expanded to RGB) and binary PGM / PPM.  JPEG (the Malaga extract) is NOT decoded:
+ * VO_ERR_UNSUPPORTED. ==== */
+
+/* host only, no GPU: size of the decoded image (channels = 1 or 3, interleaved rows) */
+int vo_image_info(const uint8_t* file_bytes, size_t n, int* H, int* W, int* channels, int* bit_depth);
+/* host only, no GPU: imread + im2uint8 -> H x W x channels uint8, row-major interleaved */
+int vo_image_decode(const uint8_t* file_bytes, size_t n, uint8_t* out, size_t out_cap);
+/* rgb2gray (main.m:20-30,54-59) of an 8-bit image: planar = 0 interleaved rows (H x W x 3 row-major),
+ * planar = 1 MATLAB's H x W x 3 column-major planes; the output has the input's pixel order.
+ * gray = floor(0.298936021293775390 R + 0.587043074451121360 G + 0.114020904255103250 B + 0.5) in fp64.
+ * on_device: both pointers are device memory and the call is asynchronous on the ctx stream. */
+int vo_rgb2gray(vo_ctx* ctx, const uint8_t* rgb, int H, int W, int planar, int on_device, uint8_t* gray);
+
+/* Decode pool: worker threads read and decode the files ahead of the consumer into pinned memory, upload
+ * on a copy stream of the pool's own and convert colour images to gray there; vo_ingest_next returns the
+ * frames in order as device images (H rows of W bytes, what vo_frame_process takes with on_device = 1)
+ * and makes the ctx stream wait for the upload.  The image stays valid until the next vo_ingest_next /
+ * vo_ingest_close on the same pool.  One consumer thread per pool. */
+typedef struct vo_ingest vo_ingest;
+typedef struct vo_ingest_opts {
+    int threads;  /* decode threads; <= 0: min(8, host threads) */
+    int depth;    /* frames in flight (ring slots); <= 0: 2 x threads */
+    int keep_rgb; /* 1: hand out colour images as interleaved RGB instead of gray */
+} vo_ingest_opts;
+int vo_ingest_open(vo_ctx* ctx, const char* const* paths, int n_paths, const vo_ingest_opts* opts, vo_ingest** out);
+int vo_ingest_count(vo_ingest* ing);
+/* VO_OK and the next frame, VO_END after the last one, or the decode error of that frame (the pool
+ * stays usable: the next call moves on to the following file) */
+int vo_ingest_next(vo_ingest* ing, const uint8_t** d_img, int* H, int* W, int* channels, int* index);
+/* copy the current frame (the one vo_ingest_next returned last) to the host; synchronises the ctx stream */
+int vo_ingest_read(vo_ingest* ing, uint8_t* host_out, size_t out_cap);
+/* summed wall time the workers spent reading + decoding + enqueueing, and the pool's actual sizes */
+int vo_ingest_stats(vo_ingest* ing, double* decode_seconds_total, int* threads, int* depth);
+int vo_ingest_close(vo_ingest* ing);
 
 #ifdef __cplusplus
 }

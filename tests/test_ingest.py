@@ -1,0 +1,196 @@
+"""Frame ingest, host side: the native PNG / PNM decoders of libvo_hip.so against the
+oracle's restatement (oracle/ingest.py) and against Pillow as an independent decoder, and the dataset
+loaders' bookkeeping against utils/dataLoader*.m / utils/loadGeneralData.m.  No GPU needed: vo_image_info /
+vo_image_decode are host code."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ingest as oi
+from visual_odometry_amd import _lib, ingest
+
+PIL_Image = pytest.importorskip("PIL.Image")
+
+
+def textured(rng, h, w, c=None):
+    a = rng.integers(0, 256, (h, w) if c is None else (h, w, c)).astype(np.float64)
+    for ax in (0, 1):
+        a = (a + np.roll(a, 1, ax) + np.roll(a, -1, ax) + np.roll(a, 2, ax)) / 4
+    return a.astype(np.uint8)
+
+
+def pil_png(img, mode=None, **kw):
+    b = io.BytesIO()
+    PIL_Image.fromarray(img, mode).save(b, "PNG", **kw)
+    return b.getvalue()
+
+
+def expect_of(img):
+    if img.ndim == 2 or img.shape[2] == 3:
+        return img
+    return img[..., 0] if img.shape[2] == 2 else img[..., :3]
+
+
+@pytest.mark.parametrize("shape", [(33, 47), (33, 47, 3), (12, 9, 4), (12, 9, 2), (1, 1), (5, 1, 3), (1, 7)])
+@pytest.mark.parametrize("filters", [None, [0], [1], [2], [3], [4], [2, 4, 3]])
+def test_every_row_filter_and_colour_type(shape, filters):
+    img = textured(np.random.default_rng(sum(shape)), *shape)
+    data = oi.png_encode(img, filters)
+    exp = expect_of(img)
+    assert np.array_equal(ingest.imdecode(data), exp)          # product decoder
+    assert np.array_equal(oi.png_decode(data), exp)            # oracle
+    if img.ndim == 2 or img.shape[2] == 3:                     # independent decoder
+        assert np.array_equal(np.asarray(PIL_Image.open(io.BytesIO(data))), exp)
+
+
+def test_files_written_by_another_encoder():
+    rng = np.random.default_rng(5)
+    for mode, img in [("L", textured(rng, 61, 83)), ("RGB", textured(rng, 40, 57, 3)), ("RGBA", textured(rng, 20, 31, 4)),
+                      ("LA", textured(rng, 20, 31, 2))]:
+        data = pil_png(img, mode)
+        assert np.array_equal(ingest.imdecode(data), expect_of(img)), mode
+        assert np.array_equal(oi.png_decode(data), expect_of(img)), mode
+
+
+def test_sixteen_bit_palette_and_packed_samples():
+    rng = np.random.default_rng(6)
+    a16 = rng.integers(0, 65536, (19, 23)).astype(np.uint16)
+    a16[0, :4] = [0, 128, 129, 65535]                          # im2uint8 rounds at x.5: 128/257 -> 0, 129/257 -> 1
+    data = pil_png(a16)
+    exp = np.round(a16.astype(np.float64) / 257.0).astype(np.uint8)
+    assert np.array_equal(ingest.imdecode(data), exp) and np.array_equal(oi.png_decode(data), exp)
+    assert np.array_equal(ingest.im2uint8(a16), exp)
+    for colours, bits in ((16, 4), (4, 2), (200, 8)):
+        pim = PIL_Image.fromarray(textured(rng, 30, 33, 3), "RGB").quantize(colours)
+        b = io.BytesIO(); pim.save(b, "PNG", bits=bits)
+        exp = np.asarray(pim.convert("RGB"))
+        assert np.array_equal(ingest.imdecode(b.getvalue()), exp) and np.array_equal(oi.png_decode(b.getvalue()), exp)
+    bim = PIL_Image.fromarray(textured(rng, 30, 35) > 128)
+    b = io.BytesIO(); bim.save(b, "PNG")
+    exp = np.asarray(bim).astype(np.uint8) * 255
+    assert np.array_equal(ingest.imdecode(b.getvalue()), exp) and np.array_equal(oi.png_decode(b.getvalue()), exp)
+
+
+def test_pnm():
+    rng = np.random.default_rng(7)
+    g, c = textured(rng, 17, 21), textured(rng, 9, 13, 3)
+    for data, exp in ((b"P5\n# a comment\n21 17\n255\n" + g.tobytes(), g), (b"P6 13 9 255\n" + c.tobytes(), c)):
+        assert np.array_equal(ingest.imdecode(data), exp) and np.array_equal(oi.pnm_decode(data), exp)
+    low = (g // 16).astype(np.uint8)                            # maxval 15 is rescaled to 0..255
+    data = b"P5 21 17 15\n" + low.tobytes()
+    assert np.array_equal(ingest.imdecode(data), oi.pnm_decode(data))
+    assert np.array_equal(ingest.imdecode(data), np.round(low * 17.0).astype(np.uint8))
+    wide = rng.integers(0, 1024, (4, 5)).astype(">u2")
+    data = b"P5 5 4 1023\n" + wide.tobytes()
+    assert np.array_equal(ingest.imdecode(data), oi.pnm_decode(data))
+
+
+def test_broken_files_are_errors_not_crashes():
+    img = textured(np.random.default_rng(8), 20, 20)
+    good = oi.png_encode(img)
+    lib = _lib.load()
+
+    def rc_of(data):
+        buf = np.frombuffer(data, np.uint8)
+        out = np.zeros(400 * 3, np.uint8)
+        return lib.vo_image_decode(_lib.ptr(buf), len(buf), _lib.ptr(out), out.size)
+    assert rc_of(good) == 0
+    assert rc_of(good[:len(good) // 2]) == -2                   # truncated
+    flipped = bytearray(good); flipped[60] ^= 0x40              # inside the first IDAT: checksum mismatch
+    assert rc_of(bytes(flipped)) == -2
+    hdr = bytearray(good); hdr[16 + 3] ^= 1                     # IHDR width changed, CRC now wrong
+    assert rc_of(bytes(hdr)) == -2
+    assert rc_of(b"\xff\xd8\xff\xe0" + b"\0" * 64) == -5        # JPEG: unsupported, says so
+    assert rc_of(b"GIF89a" + b"\0" * 64) == -5
+    assert rc_of(b"P5 3 3 255\n" + b"\0" * 5) == -2             # PNM data truncated
+    b = io.BytesIO(); PIL_Image.fromarray(img).save(b, "PNG", interlace=True)
+    data = b.getvalue()
+    if data[28] == 1:                                          # only if this Pillow really wrote Adam7
+        assert rc_of(data) == -5
+    buf = np.frombuffer(good, np.uint8)
+    small = np.zeros(10, np.uint8)
+    assert lib.vo_image_decode(_lib.ptr(buf), len(buf), _lib.ptr(small), small.size) == -2   # output too small
+    with pytest.raises(_lib.VoError):
+        ingest.imdecode(good[:40])
+
+
+def test_rgb2gray_definition():
+    """N11 on the corner cases of the rounding; the GPU kernel is held to this in test_gpu_ingest.py."""
+    px = np.array([[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [1, 1, 1], [2, 1, 0]], np.uint8)
+    g = oi.rgb2gray(px)
+    assert list(g[:6]) == [0, 255, 76, 150, 29, 1]
+    assert g[6] == int(np.floor(0.298936021293775390 * 2 + 0.587043074451121360 + 0.5))
+    rng = np.random.default_rng(9)
+    rgb = rng.integers(0, 256, (50, 60, 3), dtype=np.uint8)
+    ref = np.asarray(PIL_Image.fromarray(rgb, "RGB").convert("L")).astype(int)   # ITU-R 601 integer weights: close, not equal
+    assert np.abs(oi.rgb2gray(rgb).astype(int) - ref).max() <= 1
+
+
+def make_tree(tmp_path, rng):
+    kitti = tmp_path / "kitti"
+    (kitti / "00" / "image_0").mkdir(parents=True)
+    (kitti / "poses").mkdir()
+    frames = [textured(rng, 24, 40) for _ in range(4)]
+    for i, f in enumerate(frames):
+        (kitti / "00" / "image_0" / ("%06d.png" % i)).write_bytes(oi.png_encode(f))
+    poses = rng.normal(size=(4, 12))
+    np.savetxt(kitti / "poses" / "00.txt", poses)
+    parking = tmp_path / "parking"
+    (parking / "images").mkdir(parents=True)
+    colour = [textured(rng, 24, 40, 3) for _ in range(3)]
+    for i, f in enumerate(colour):
+        (parking / "images" / ("img_%05d.png" % i)).write_bytes(oi.png_encode(f))
+    (parking / "K.txt").write_text("331.37, 0, 320,\n0, 369.568, 240,\n0, 0, 1,\n")
+    pp = rng.normal(size=(3, 12))
+    np.savetxt(parking / "poses.txt", pp)
+    malaga = tmp_path / "malaga"
+    d = malaga / ingest.MALAGA_DIR
+    d.mkdir(parents=True)
+    for i in range(3):
+        (d / ("img_CAMERA1_%03d_left.jpg" % i)).write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
+        (d / ("img_CAMERA1_%03d_right.jpg" % i)).write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
+    return kitti, frames, poses, parking, colour, pp, malaga
+
+
+def test_dataset_loaders(tmp_path):
+    rng = np.random.default_rng(10)
+    kitti, frames, poses, parking, colour, pp, malaga = make_tree(tmp_path, rng)
+    ld = ingest.dataLoaderKitti(kitti, last_frame=3)
+    assert np.array_equal(ld.camParams.IntrinsicMatrix, ingest.KITTI_K.T) and ld.index == 0 and not ld.finished
+    np.testing.assert_allclose(ld.ground_truth_data, poses[:, [3, 11]])      # [end-8 end] of 12 columns
+    for i in range(4):
+        img, gt = ld.next()
+        assert np.array_equal(img, frames[i])
+        np.testing.assert_allclose(gt, poses[i, [3, 11]])
+    assert ld.finished
+    with pytest.raises(AssertionError):
+        ld.next()
+    ld.reset(2)
+    assert ld.index == 2 and not ld.finished
+    assert np.array_equal(ld.retrieveFrame(1)[0], frames[1])
+    with pytest.raises(AssertionError):
+        ld.reset(9)
+    assert ingest.dataLoaderKitti(kitti).last_frame == 4540                   # utils/dataLoaderKitti.m:49
+
+    lp = ingest.dataLoaderParking(parking, last_frame=2)
+    np.testing.assert_allclose(lp.camParams.K, [[331.37, 0, 320], [0, 369.568, 240], [0, 0, 1]])
+    img, gt = lp.next()
+    assert np.array_equal(img, colour[0]) and img.shape == (24, 40, 3)        # imread only: rgb2gray is the caller's step
+    np.testing.assert_allclose(gt, pp[0, [3, 11]])
+    assert ingest.dataLoaderParking(parking).last_frame == 598
+
+    lm = ingest.dataLoaderMalaga(malaga)
+    assert lm.last_frame == 2 and all(p.endswith("_left.jpg") for p in lm.left_images_dirs)
+    with pytest.raises(_lib.VoError):                                          # JPEG is not decoded, and says so
+        lm.next()
+
+    cam, gt, last = ingest.loadGeneralData(0, kitti_path=str(kitti))
+    assert last == 4540 and gt.shape == (4, 2)
+    cam, gt, last = ingest.loadGeneralData(1, malaga_path=str(malaga))
+    assert last == 3 and gt.shape == (0, 2) and np.array_equal(cam.K, ingest.MALAGA_K)
+    cam, gt, last = ingest.loadGeneralData(2, parking_path=str(parking))
+    assert last == 598 and cam.K[1, 1] == 369.568
+    with pytest.raises(AssertionError):
+        ingest.loadGeneralData(3)

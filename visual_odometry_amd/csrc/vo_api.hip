@@ -18,6 +18,7 @@ const char* vo_strerror(int code) {
         case VO_ERR_HIP: return "HIP runtime error";
         case VO_ERR_OOM: return "out of device memory";
         case VO_ERR_UNSUPPORTED: return "unsupported configuration";
+        case VO_END: return "end of the sequence";
         default: return "unknown error";
     }
 }

@@ -38,7 +38,7 @@ struct vo_ctx {
     vo_pyr frames[VO_NUM_FRAME_SLOTS];
     uint64_t clock = 0;
     unsigned long long* d_counters = nullptr; // VO_COUNTER_SHARDS x 4 u64
-    vo_buf scratch[16];                        // purpose-indexed scratch (see vo_api.hip)
+    vo_buf scratch[17];                        // purpose-indexed scratch (see vo_api.hip; [16] = vo_rgb2gray staging)
     std::string last_error;
 };
 
