@@ -156,3 +156,53 @@ def test_stream_feeds_the_frame_loop_like_host_images(ctx, tmp_path):
     sa, sb = a.get_state(), b.get_state()
     assert np.array_equal(sa.landmarks, sb.landmarks) and np.array_equal(sa.candidate_keypoints, sb.candidate_keypoints)
     fs.close(); a.close(); b.close()
+
+
+JPEG_DIR = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "jpeg")
+
+
+@pytest.mark.parametrize("keep_rgb", [False, True])
+def test_pool_decodes_jpeg_fixtures_on_the_device(ctx, keep_rgb):
+    """Committed JPEG files (gray, 4:4:4, 4:2:2, 4:2:0, restart intervals, optimised tables): host Huffman decoding,
+    then IDCT + upsampling + colour conversion (+ rgb2gray) on the GPU, bit-exact against the oracle's N12 / N11."""
+    import os
+    exp = np.load(os.path.join(JPEG_DIR, "jpeg_expected.npz"), allow_pickle=False)
+    names = sorted(exp.files)
+    fs = ingest.FrameStream([os.path.join(JPEG_DIR, n + ".jpg") for n in names] * 2, threads=2, depth=3, keep_rgb=keep_rgb)
+    for k, img in enumerate(fs):
+        e = exp[names[k % len(names)]]
+        assert np.array_equal(oi.jpeg_decode(open(fs.paths[k], "rb").read()), e)       # the oracle itself, on the box
+        want = e if (keep_rgb or e.ndim == 2) else oi.rgb2gray(e)
+        assert img.shape == want.shape, names[k % len(names)]
+        assert np.array_equal(fs.read(), want), names[k % len(names)]
+    fs.close()
+
+
+def test_pool_jpeg_at_malaga_size_and_mixed_with_png(ctx, tmp_path):
+    """800 x 600 colour JPEGs (the Malaga extract's shape) and odd sizes: the device back half equals the host decoder
+    (itself pinned to the oracle and to Pillow in tests/test_ingest.py) byte for byte; PNG files in between make the
+    slots change roles."""
+    PIL_Image = pytest.importorskip("PIL.Image")
+    import io
+    rng = np.random.default_rng(21)
+    paths, want_gray, want_rgb = [], [], []
+    for i, (shape, sub, q) in enumerate([((600, 800, 3), 2, 85), ((600, 800, 3), 1, 92), ((601, 799, 3), 2, 70),
+                                         ((600, 800), 0, 80), ((50, 70, 3), 0, 95), ((600, 800, 3), 0, 60)]):
+        img = textured(rng, *shape)
+        b = io.BytesIO()
+        PIL_Image.fromarray(img).save(b, "JPEG", quality=q, subsampling=sub, restart_marker_rows=(2 if i == 1 else 0))
+        p = tmp_path / ("j%02d.jpg" % i)
+        p.write_bytes(b.getvalue())
+        dec = ingest.imdecode(b.getvalue())
+        assert np.array_equal(dec, np.asarray(PIL_Image.open(io.BytesIO(b.getvalue()))))
+        paths.append(str(p)); want_rgb.append(dec); want_gray.append(oi.to_gray(dec))
+        png = textured(rng, 40, 60, 3)
+        p = tmp_path / ("p%02d.png" % i)
+        p.write_bytes(oi.png_encode(png))
+        paths.append(str(p)); want_rgb.append(png); want_gray.append(oi.rgb2gray(png))
+    for keep_rgb, want in ((False, want_gray), (True, want_rgb)):
+        fs = ingest.FrameStream(paths, threads=3, depth=2, keep_rgb=keep_rgb)
+        for k, img in enumerate(fs):
+            assert img.shape == want[k].shape, k
+            assert np.array_equal(fs.read(), want[k]), k
+        fs.close()

@@ -102,7 +102,7 @@ def test_broken_files_are_errors_not_crashes():
     assert rc_of(bytes(flipped)) == -2
     hdr = bytearray(good); hdr[16 + 3] ^= 1                     # IHDR width changed, CRC now wrong
     assert rc_of(bytes(hdr)) == -2
-    assert rc_of(b"\xff\xd8\xff\xe0" + b"\0" * 64) == -5        # JPEG: unsupported, says so
+    assert rc_of(b"\xff\xd8\xff\xe0" + b"\0" * 64) == -2        # JPEG signature, nothing behind it
     assert rc_of(b"GIF89a" + b"\0" * 64) == -5
     assert rc_of(b"P5 3 3 255\n" + b"\0" * 5) == -2             # PNM data truncated
     b = io.BytesIO(); PIL_Image.fromarray(img).save(b, "PNG", interlace=True)
@@ -114,6 +114,59 @@ def test_broken_files_are_errors_not_crashes():
     assert lib.vo_image_decode(_lib.ptr(buf), len(buf), _lib.ptr(small), small.size) == -2   # output too small
     with pytest.raises(_lib.VoError):
         ingest.imdecode(good[:40])
+
+
+JPEG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg")
+
+
+def test_jpeg_fixtures_native_oracle_and_expected_agree():
+    """The committed files (tests/golden/make_jpeg_fixtures.py): gray, 4:4:4, 4:2:2, 4:2:0, restart intervals,
+    optimised Huffman tables.  Expected pixels = the oracle's N12 decode, which equalled Pillow's when written."""
+    exp = np.load(os.path.join(JPEG_DIR, "jpeg_expected.npz"), allow_pickle=False)
+    assert len(exp.files) == 6
+    for name in exp.files:
+        data = open(os.path.join(JPEG_DIR, name + ".jpg"), "rb").read()
+        assert np.array_equal(ingest.imdecode(data), exp[name]), name     # product (host decoder)
+        assert np.array_equal(oi.jpeg_decode(data), exp[name]), name      # oracle
+        assert np.array_equal(np.asarray(PIL_Image.open(io.BytesIO(data))), exp[name]), name   # independent decoder
+
+
+@pytest.mark.parametrize("sub", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(8, 8, 3), (17, 16, 3), (37, 53, 3), (41, 23), (600, 800, 3)])
+def test_jpeg_against_an_independent_decoder(shape, sub):
+    if len(shape) == 2 and sub:
+        pytest.skip("gray files have no chroma")
+    rng = np.random.default_rng(shape[0] + sub)
+    img = textured(rng, *shape)
+    for q, kw in ((35, {}), (90, {"optimize": True}), (100, {}), (75, {"restart_marker_rows": 1})):
+        b = io.BytesIO()
+        PIL_Image.fromarray(img).save(b, "JPEG", quality=q, subsampling=sub, **kw)
+        data = b.getvalue()
+        ref = np.asarray(PIL_Image.open(io.BytesIO(data)))
+        assert np.array_equal(ingest.imdecode(data), ref), (q, kw)
+        if shape[0] * shape[1] <= 2000:
+            assert np.array_equal(oi.jpeg_decode(data), ref), (q, kw)
+
+
+def test_jpeg_what_is_not_decoded_says_so():
+    lib = _lib.load()
+    img = textured(np.random.default_rng(3), 40, 40, 3)
+
+    def rc_of(data):
+        buf = np.frombuffer(data, np.uint8)
+        out = np.zeros(40 * 40 * 3, np.uint8)
+        return lib.vo_image_decode(_lib.ptr(buf), len(buf), _lib.ptr(out), out.size)
+    b = io.BytesIO(); PIL_Image.fromarray(img).save(b, "JPEG", progressive=True)
+    assert rc_of(b.getvalue()) == -5
+    b = io.BytesIO(); PIL_Image.fromarray(img).convert("CMYK").save(b, "JPEG")
+    assert rc_of(b.getvalue()) == -5
+    b = io.BytesIO(); PIL_Image.fromarray(img).save(b, "JPEG", quality=80)
+    good = b.getvalue()
+    assert rc_of(good) == 0
+    assert rc_of(good[:len(good) - 200]) == -2                   # scan cut short
+    assert rc_of(good[:100]) == -2                               # cut inside the tables
+    bad = bytearray(good); i = good.index(b"\xff\xc4"); bad[i + 5:i + 21] = b"\xff" * 16   # impossible code counts
+    assert rc_of(bytes(bad)) == -2
 
 
 def test_rgb2gray_definition():
@@ -148,15 +201,20 @@ def make_tree(tmp_path, rng):
     malaga = tmp_path / "malaga"
     d = malaga / ingest.MALAGA_DIR
     d.mkdir(parents=True)
+    left = []
     for i in range(3):
-        (d / ("img_CAMERA1_%03d_left.jpg" % i)).write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
-        (d / ("img_CAMERA1_%03d_right.jpg" % i)).write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
-    return kitti, frames, poses, parking, colour, pp, malaga
+        for side in ("left", "right"):
+            b = io.BytesIO()
+            PIL_Image.fromarray(textured(rng, 24, 40, 3)).save(b, "JPEG", quality=90)
+            (d / ("img_CAMERA1_%03d_%s.jpg" % (i, side))).write_bytes(b.getvalue())
+            if side == "left":
+                left.append(np.asarray(PIL_Image.open(io.BytesIO(b.getvalue()))))
+    return kitti, frames, poses, parking, colour, pp, malaga, left
 
 
 def test_dataset_loaders(tmp_path):
     rng = np.random.default_rng(10)
-    kitti, frames, poses, parking, colour, pp, malaga = make_tree(tmp_path, rng)
+    kitti, frames, poses, parking, colour, pp, malaga, left = make_tree(tmp_path, rng)
     ld = ingest.dataLoaderKitti(kitti, last_frame=3)
     assert np.array_equal(ld.camParams.IntrinsicMatrix, ingest.KITTI_K.T) and ld.index == 0 and not ld.finished
     np.testing.assert_allclose(ld.ground_truth_data, poses[:, [3, 11]])      # [end-8 end] of 12 columns
@@ -183,8 +241,10 @@ def test_dataset_loaders(tmp_path):
 
     lm = ingest.dataLoaderMalaga(malaga)
     assert lm.last_frame == 2 and all(p.endswith("_left.jpg") for p in lm.left_images_dirs)
-    with pytest.raises(_lib.VoError):                                          # JPEG is not decoded, and says so
-        lm.next()
+    for i in range(3):                                                         # the LEFT images, in order (:56)
+        img, gt = lm.next()
+        assert np.array_equal(img, left[i]) and gt.size == 0
+    assert lm.finished
 
     cam, gt, last = ingest.loadGeneralData(0, kitti_path=str(kitti))
     assert last == 4540 and gt.shape == (4, 2)

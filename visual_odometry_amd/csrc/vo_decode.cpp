@@ -1,9 +1,10 @@
 // vo_decode.cpp -- host-side image decoders of the frame ingest: PNG (zlib inflate +
 // the five row filters, every colour type, 1..16 bit, non-interlaced) and binary PGM/PPM -> 8-bit gray or
-// interleaved RGB.  What `imread` (+ im2uint8) does at main.m:15-30,52-59, utils/dataLoaderKitti.m:29,
+// interleaved RGB; baseline JPEG through vo_jpeg.cpp.  What `imread` (+ im2uint8) does at main.m:15-30,52-59, utils/dataLoaderKitti.m:29,
 // utils/dataLoaderParking.m:29.  Plain C++ built with g++ (its code for the serial filter chains runs about
 // twice as fast as the HIP host compiler's); no HIP in here.
 #include "vo_decode.h"
+#include "vo_jpeg.h"
 
 #include <zlib.h>
 
@@ -125,10 +126,12 @@ int image_header(const uint8_t* d, size_t n, ImgHdr* h, std::string* err) {
     if (n >= 8 && memcmp(d, PNG_MAGIC, 8) == 0) return png_header(d, n, h, err);
     if (n >= 3 && d[0] == 'P' && (d[1] == '5' || d[1] == '6')) return pnm_header(d, n, h, err);
     if (n >= 2 && d[0] == 0xff && d[1] == 0xd8) {
-        *err = "jpeg files are not decoded by this build";
-        return VO_ERR_UNSUPPORTED;
+        const int rc = vo_jpeg_header(d, n, &h->W, &h->H, &h->channels, err);
+        h->bit_depth = 8;
+        h->kind = 3;
+        return rc;
     }
-    *err = "unknown image format (PNG and binary PGM/PPM are decoded)";
+    *err = "unknown image format (PNG, baseline JPEG and binary PGM/PPM are decoded)";
     return VO_ERR_UNSUPPORTED;
 }
 
@@ -341,6 +344,16 @@ int pnm_decode(const uint8_t* d, size_t n, const ImgHdr& h, uint8_t* out) {
 int image_decode(const uint8_t* d, size_t n, const ImgHdr& h, uint8_t* out, DecodeScratch* sc, std::string* err) {
     if (h.kind == 1) return png_decode(d, n, h, out, sc, err);
     if (h.kind == 2) return pnm_decode(d, n, h, out);
+    if (h.kind == 3) {
+        JpegFrame f;
+        int rc = vo_jpeg_layout(d, n, &f, err);
+        if (rc != VO_OK) return rc;
+        if (sc->coef.size() < f.nblocks * 64) sc->coef.resize(f.nblocks * 64);
+        rc = vo_jpeg_entropy(d, n, &f, sc->coef.data(), err);
+        if (rc != VO_OK) return rc;
+        vo_jpeg_reconstruct(f, sc->coef.data(), out, &sc->planes);
+        return VO_OK;
+    }
     *err = "no decoder";
     return VO_ERR_UNSUPPORTED;
 }

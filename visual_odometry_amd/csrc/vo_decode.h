@@ -10,7 +10,7 @@ struct ImgHdr {
     int H = 0, W = 0;
     int channels = 0;   // of the decoded output: 1 or 3
     int bit_depth = 0;  // of the file's samples
-    int kind = 0;       // 1 PNG, 2 PNM
+    int kind = 0;       // 1 PNG, 2 PNM, 3 JPEG
     // PNG
     int color_type = 0, interlace = 0;
     // PNM
@@ -22,6 +22,8 @@ struct DecodeScratch {  // per worker thread, grow-only
     std::vector<uint8_t> raw;
     std::vector<uint8_t> zero;
     std::vector<uint8_t> file;
+    std::vector<int16_t> coef;    // JPEG coefficient blocks
+    std::vector<uint8_t> planes;  // JPEG component planes
 };
 
 // each returns VO_OK or a VO_ERR_* code and says why in *err

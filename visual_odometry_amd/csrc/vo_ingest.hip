@@ -19,6 +19,7 @@
 
 #include "vo_common.h"
 #include "vo_decode.h"
+#include "vo_jpeg.h"
 
 namespace {
 
@@ -76,6 +77,126 @@ int launch_rgb2gray(hipStream_t s, const uint8_t* d_in, long n, int planar, uint
     return hipGetLastError() == hipSuccess ? VO_OK : VO_ERR_HIP;
 }
 
+// ------------------------------------------------------------------------------------------------
+// JPEG back half (device): what follows the serial bit stream.  The host's Huffman decoder leaves quantised
+// coefficient blocks in pinned memory; dequantisation, the 8x8 inverse DCT, chroma upsampling, YCbCr -> RGB
+// and rgb2gray run here, with the arithmetic of definition N12 shared with the host decoder through
+// vo_jpeg.h, so both produce the same bytes.
+// ------------------------------------------------------------------------------------------------
+struct JpegDev {
+    int W, H, nc, hs, vs;
+    int bw[3], bh[3], dw[3], dh[3];
+    unsigned block0[3], plane0[3];  // first block / first plane byte of each component
+    unsigned nblocks;
+    uint16_t qt[3][64];
+};
+
+// 8 threads per block: thread j does column j, then row j; 32 blocks per workgroup.
+// LDS image of a block: element (r, c) at r*9 + c, blocks 72 words apart: both passes are conflict-free.
+__global__ void __launch_bounds__(256) k_jpeg_idct(const int16_t* __restrict__ coef, JpegDev a, uint8_t* __restrict__ planes) {
+    __shared__ int ws[32 * 72];
+    const int t = threadIdx.x, lb = t >> 3, j = t & 7;
+    const unsigned b = blockIdx.x * 32u + (unsigned)lb;
+    const bool live = b < a.nblocks;
+    const int c = (a.nc == 3 && b >= a.block0[2]) ? 2 : ((a.nc == 3 && b >= a.block0[1]) ? 1 : 0);
+    int* w = ws + lb * 72;
+    if (live) {
+        const int16_t* blk = coef + (size_t)b * 64;
+        int in[8], o[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) in[r] = (int)blk[r * 8 + j] * (int)a.qt[c][r * 8 + j];
+        vo_jpeg_idct8(in, o);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[r * 9 + j] = (o[r] + 1024) >> 11;
+    }
+    __syncthreads();
+    if (!live) return;
+    int in[8], o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) in[k] = w[j * 9 + k];
+    vo_jpeg_idct8(in, o);
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        lo |= (uint32_t)vo_jpeg_range((o[k] + 131072) >> 18) << (8 * k);
+        hi |= (uint32_t)vo_jpeg_range((o[k + 4] + 131072) >> 18) << (8 * k);
+    }
+    const unsigned rel = b - a.block0[c];
+    const unsigned by = rel / (unsigned)a.bw[c], bx = rel - by * (unsigned)a.bw[c];
+    const size_t pitch = (size_t)a.bw[c] * 8;
+    uint2* dst = reinterpret_cast<uint2*>(planes + a.plane0[c] + ((size_t)by * 8 + j) * pitch + (size_t)bx * 8);
+    *dst = make_uint2(lo, hi);
+}
+
+// four pixels of a row per thread: Y + upsampled chroma -> RGB (-> gray when to_gray); gray files: the Y plane
+__global__ void __launch_bounds__(256) k_jpeg_pixels(const uint8_t* __restrict__ planes, JpegDev a, int to_gray, int vec,
+                                                     uint8_t* __restrict__ out) {
+    const int qw = (a.W + 3) / 4;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (long)qw * a.H) return;
+    const int y = (int)(q / qw), x0 = (int)(q - (long)y * qw) * 4;
+    const uint8_t* Y = planes + a.plane0[0] + (size_t)y * a.bw[0] * 8;
+    const int och = (a.nc == 1 || to_gray) ? 1 : 3;
+    uint8_t* o = out + ((size_t)y * a.W + x0) * och;
+    unsigned px[12];
+    const int cnt = a.W - x0 < 4 ? a.W - x0 : 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x0 + (k < cnt ? k : cnt - 1);
+        if (a.nc == 1) {
+            px[k] = Y[x];
+            continue;
+        }
+        const int pc = a.bw[1] * 8;
+        const int cb = vo_jpeg_chroma(planes + a.plane0[1], pc, a.dw[1], a.dh[1], a.hs, a.vs, x, y);
+        const int cr = vo_jpeg_chroma(planes + a.plane0[2], pc, a.dw[2], a.dh[2], a.hs, a.vs, x, y);
+        int r, g, b;
+        vo_jpeg_ycc(Y[x], cb, cr, &r, &g, &b);
+        if (to_gray) px[k] = gray_of((unsigned)r, (unsigned)g, (unsigned)b);
+        else {
+            px[3 * k] = (unsigned)r;
+            px[3 * k + 1] = (unsigned)g;
+            px[3 * k + 2] = (unsigned)b;
+        }
+    }
+    if (vec && cnt == 4) {
+        uint32_t* ow = reinterpret_cast<uint32_t*>(o);
+#pragma unroll
+        for (int wd = 0; wd < 3; ++wd)
+            if (wd < och) ow[wd] = px[4 * wd] | (px[4 * wd + 1] << 8) | (px[4 * wd + 2] << 16) | (px[4 * wd + 3] << 24);
+        return;
+    }
+    for (int i = 0; i < cnt * och; ++i) o[i] = (uint8_t)px[i];
+}
+
+size_t jpeg_plane_bytes(const JpegFrame& f) {
+    size_t t = 0;
+    for (int c = 0; c < f.nc; ++c) t += (size_t)f.comp[c].bw * 8 * f.comp[c].bh * 8;
+    return t;
+}
+
+int launch_jpeg_back_half(hipStream_t s, const JpegFrame& f, const int16_t* d_coef, uint8_t* d_planes, int to_gray,
+                          uint8_t* d_out) {
+    JpegDev a;
+    memset(&a, 0, sizeof(a));
+    a.W = f.W; a.H = f.H; a.nc = f.nc; a.hs = f.hmax == 2; a.vs = f.vmax == 2;
+    unsigned p0 = 0;
+    for (int c = 0; c < 3; ++c) {
+        const JpegComp& k = f.comp[c < f.nc ? c : 0];
+        a.bw[c] = k.bw; a.bh[c] = k.bh; a.dw[c] = k.dw; a.dh[c] = k.dh;
+        a.block0[c] = c < f.nc ? (unsigned)k.block0 : (unsigned)f.nblocks;
+        a.plane0[c] = c < f.nc ? p0 : 0;
+        if (c < f.nc) p0 += (unsigned)k.bw * 8u * (unsigned)k.bh * 8u;
+        memcpy(a.qt[c], f.qt[c < f.nc ? c : 0], sizeof(a.qt[c]));
+    }
+    a.nblocks = (unsigned)f.nblocks;
+    hipLaunchKernelGGL(k_jpeg_idct, dim3((a.nblocks + 31) / 32), dim3(256), 0, s, d_coef, a, d_planes);
+    const long quads = (long)((f.W + 3) / 4) * f.H;
+    const int vec = f.W % 4 == 0 && (uintptr_t)d_out % 4 == 0;
+    hipLaunchKernelGGL(k_jpeg_pixels, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, d_planes, a, to_gray, vec, d_out);
+    return hipGetLastError() == hipSuccess ? VO_OK : VO_ERR_HIP;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -87,8 +208,10 @@ struct vo_ingest {
         size_t h_cap = 0;
         uint8_t* d_raw = nullptr;
         size_t d_raw_cap = 0;
-        uint8_t* d_gray = nullptr;
+        uint8_t* d_gray = nullptr;  // what a device pass (rgb2gray, the JPEG back half) writes
         size_t d_gray_cap = 0;
+        uint8_t* d_aux = nullptr;   // JPEG component planes
+        size_t d_aux_cap = 0;
         hipEvent_t ready = nullptr;     // copy stream: upload (+ rgb2gray) of this slot done
         hipEvent_t released = nullptr;  // consumer stream: everything that read this slot's image enqueued before it
         bool uploaded = false, has_released = false, gray_pass = false;
@@ -114,7 +237,14 @@ struct vo_ingest {
 
 namespace {
 
-int slot_reserve(vo_ingest* g, vo_ingest::Slot* s, size_t raw_bytes, size_t gray_bytes) {
+int slot_reserve(vo_ingest* g, vo_ingest::Slot* s, size_t raw_bytes, size_t gray_bytes, size_t aux_bytes = 0) {
+    if (s->d_aux_cap < aux_bytes) {
+        if (s->d_aux) (void)hipFree(s->d_aux);
+        s->d_aux = nullptr;
+        s->d_aux_cap = 0;
+        if (hipMalloc((void**)&s->d_aux, aux_bytes) != hipSuccess) return VO_ERR_OOM;
+        s->d_aux_cap = aux_bytes;
+    }
     if (s->h_cap < raw_bytes) {
         if (s->h_pin) (void)hipHostFree(s->h_pin);
         s->h_pin = nullptr;
@@ -162,7 +292,40 @@ void ingest_worker(vo_ingest* g) {
         ImgHdr h;
         int rc = vo_dec_read_file(g->paths[i].c_str(), &sc.file, &fn, &err);
         if (rc == VO_OK) rc = vo_dec_header(sc.file.data(), fn, &h, &err);
-        if (rc == VO_OK) {
+        if (rc == VO_OK && h.kind == 3) {
+            // JPEG: the bit stream is decoded here, everything after it on the device
+            JpegFrame f;
+            rc = vo_jpeg_layout(sc.file.data(), fn, &f, &err);
+            const size_t raw_bytes = f.nblocks * 64 * sizeof(int16_t);
+            const int och = (f.nc == 1 || g->to_gray) ? 1 : 3;
+            if (rc == VO_OK && s->uploaded && hipEventSynchronize(s->ready) != hipSuccess) rc = VO_ERR_HIP;
+            if (rc == VO_OK) {
+                std::lock_guard<std::mutex> hl(g->hip_mu);
+                rc = slot_reserve(g, s, raw_bytes, (size_t)f.H * f.W * och, jpeg_plane_bytes(f));
+                if (rc != VO_OK) err = "device or pinned allocation failed";
+            }
+            if (rc == VO_OK) rc = vo_jpeg_entropy(sc.file.data(), fn, &f, reinterpret_cast<int16_t*>(s->h_pin), &err);
+            if (rc == VO_OK) {
+                std::lock_guard<std::mutex> hl(g->hip_mu);
+                hipError_t e = hipSuccess;
+                if (s->has_released) e = hipStreamWaitEvent(g->copy, s->released, 0);
+                if (e == hipSuccess) e = hipMemcpyAsync(s->d_raw, s->h_pin, raw_bytes, hipMemcpyHostToDevice, g->copy);
+                if (e == hipSuccess && launch_jpeg_back_half(g->copy, f, reinterpret_cast<const int16_t*>(s->d_raw), s->d_aux,
+                                                             g->to_gray, s->d_gray) != VO_OK)
+                    e = hipErrorLaunchFailure;
+                if (e == hipSuccess) e = hipEventRecord(s->ready, g->copy);
+                if (e != hipSuccess) {
+                    rc = VO_ERR_HIP;
+                    err = std::string("upload: ") + hipGetErrorString(e);
+                } else {
+                    s->uploaded = true;
+                }
+            }
+            s->H = f.H;
+            s->W = f.W;
+            s->ch = och;
+            s->gray_pass = true;  // the image handed out is the device pass's output
+        } else if (rc == VO_OK) {
             const size_t raw_bytes = (size_t)h.H * h.W * h.channels;
             const bool gray_pass = h.channels == 3 && g->to_gray;
             // the pinned buffer is rewritten below: its last upload must have left it
@@ -392,6 +555,7 @@ int vo_ingest_close(vo_ingest* g) {
         if (s.h_pin) (void)hipHostFree(s.h_pin);
         if (s.d_raw) (void)hipFree(s.d_raw);
         if (s.d_gray) (void)hipFree(s.d_gray);
+        if (s.d_aux) (void)hipFree(s.d_aux);
         if (s.ready) (void)hipEventDestroy(s.ready);
         if (s.released) (void)hipEventDestroy(s.released);
     }
