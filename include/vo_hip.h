@@ -265,8 +265,11 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
  * them (main.m:15-30,52-59; utils/dataLoaderKitti.m:29, utils/dataLoaderParking.m:29,
  * utils/dataLoaderMalaga.m:29-30).  Decoded: PNG (non-interlaced; every colour type and bit depth;
  * alpha dropped; 16-bit samples reduced as im2uint8 does, round(x / 257); gray below 8 bits scaled to
- * 0..255; palette expanded to RGB) and binary PGM / PPM.  JPEG (the Malaga extract) is NOT decoded:
- * VO_ERR_UNSUPPORTED. ==== */
+ * 0..255; palette expanded to RGB), baseline JPEG (8-bit sequential Huffman, gray or YCbCr with chroma at
+ * 1:1 or 2:1 per axis, restart intervals; progressive / arithmetic / CMYK / multi-scan files are
+ * VO_ERR_UNSUPPORTED) and binary PGM / PPM.  In the decode pool a JPEG's bit stream is decoded on the
+ * host and everything after it (dequantisation, inverse DCT, chroma upsampling, YCbCr -> RGB, rgb2gray)
+ * runs on the device; vo_image_decode does the same arithmetic on the host, bit for bit. ==== */
 
 /* host only, no GPU: size of the decoded image (channels = 1 or 3, interleaved rows) */
 int vo_image_info(const uint8_t* file_bytes, size_t n, int* H, int* W, int* channels, int* bit_depth);

@@ -11,7 +11,8 @@
  * restate OPEN reference code (old/p3p.m, old/solveQuartic.m, old/ransacLocalization.m,
  * old/harris.m, old/selectKeypoints.m, old/linearTriangulation.m, utils/calculateAngleDeg.m,
  * modules/isInFrontOfCamera.m) follow it line by line and cite it; toolbox-internal steps are
- * DEFINED here (normative definitions N1..N10 below) from the public documentation and the
+ * DEFINED here (normative definitions N1..N10 below; N11 rgb2gray and N12 JPEG arithmetic of the
+ * frame ingest are in oracle/ingest.py) from the public documentation and the
  * Bouguet / Shi-Tomasi / Kneip / Torr-Zisserman papers.  The oracle is pinned by analytic
  * known-answer tests (tests/test_oracle_*.py) and by the fixtures under tests/golden/ that it
  * emitted itself (tests/golden/make_golden.py).

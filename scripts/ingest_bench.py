@@ -46,6 +46,43 @@ for t in threads:
           f"({1e3 * st.decode_seconds / n:.2f} ms of worker time per frame)")
     fs.close()
 
+# Malaga-shaped colour JPEGs (800 x 600, 4:2:0): Huffman decoding on the host, the rest on the device
+try:
+    import io
+    from PIL import Image                                          # fixture writer only
+    rgb = np.stack([synth.texture(600, 800, 31 + c, margin=0)[:600, :800] for c in range(3)], -1).astype(np.uint8)
+    jp = []
+    for i in range(8):
+        b = io.BytesIO()
+        Image.fromarray(np.roll(rgb, 3 * i, 1)).save(b, "JPEG", quality=90, subsampling=2)
+        jp.append(b.getvalue())
+    jpaths = []
+    for i in range(n_files):
+        p = os.path.join(tmp, "m%06d.jpg" % i)
+        with open(p, "wb") as f:
+            f.write(jp[i % 8])
+        jpaths.append(p)
+    print(f"{n_files} JPEG files of {len(jp[0]) / 1e3:.0f} kB, 800 x 600 colour 4:2:0")
+    t0 = time.perf_counter()
+    for b in jp * 4:
+        ingest.imdecode(b)
+    print(f"host-only decode (imread): {1e3 * (time.perf_counter() - t0) / 32:.2f} ms per file on one thread")
+    for t in threads:
+        fs = ingest.FrameStream(jpaths, threads=t)
+        fs.ctx.sync()
+        t0 = time.perf_counter()
+        n = sum(1 for _ in fs)
+        fs.ctx.sync()
+        dt = time.perf_counter() - t0
+        st = fs.stats()
+        print(f"jpeg pool    threads {st.threads:2d} depth {st.depth:2d}: {n / dt:7.0f} frames/s "
+              f"({1e3 * st.decode_seconds / n:.2f} ms of worker time per frame)")
+        fs.close()
+    for p in jpaths:
+        os.remove(p)
+except ImportError:
+    print("Pillow missing: no JPEG leg")
+
 # feeding the frame loop: state from the oracle-free product path (selection on frame 0 + the plane's lift)
 from visual_odometry_amd import modules
 for t in threads:

@@ -12,8 +12,9 @@ Mirrors what the reference's frame loops do per frame -- `imread`, `rgb2gray`, `
 a FrameStream whose worker threads decode ahead and upload on their own copy stream, yielding device
 images that FrameLoop.processFrame takes as they are.
 
-The decoders are native (libvo_hip.so); PNG and binary PGM/PPM are decoded, JPEG is not (Malaga's
-extract: the loader lists the files, reading one raises VoError).  There is no fallback decoder.
+The decoders are native (libvo_hip.so): PNG, baseline JPEG (Malaga's extract) and binary PGM/PPM.  In a
+FrameStream a JPEG's Huffman decoding runs on the worker threads and everything after it on the GPU.
+There is no fallback decoder.
 """
 import ctypes as C
 import os
