@@ -205,6 +205,15 @@ int vo_dev_select_candidates(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, 
                              const float* d_eu, const float* d_ev, int n_exist, const vo_sel_opts* opts,
                              float* d_out_u, float* d_out_v, int32_t* d_out_lin, double* d_out_metric,
                              int32_t* d_out_count);
+/* the same selection in two calls, so that the part that needs only the image (corner response, threshold,
+ * regional maxima: modules/selectCandidateKeypoints.m:20) runs on a side stream of the ctx beside whatever is
+ * enqueued between them (tracking, pose, triangulation), and only the part that needs the existing points
+ * (:23-33) runs where vo_dev_select_candidates would.  Results are identical to the single call.
+ * max_exist: upper bound of the n_exist that vo_dev_select_finish will pass.  One selection at a time. */
+int vo_dev_select_begin(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, const vo_sel_opts* opts, int max_exist);
+int vo_dev_select_finish(vo_ctx* ctx, int u_is_rows, const float* d_eu, const float* d_ev, int n_exist,
+                         float* d_out_u, float* d_out_v, int32_t* d_out_lin, double* d_out_metric,
+                         int32_t* d_out_count);
 /* row-major device arrays: xy C x 2, poses P x 12, X C x 3 */
 int vo_dev_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, const double* d_poses0,
                        int P, const int32_t* d_pose_idx, int C, const double* d_pose1,

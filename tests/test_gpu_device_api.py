@@ -1,0 +1,83 @@
+"""Device-pointer selection entry points (vo_dev_select_candidates and its two-call form vo_dev_select_begin /
+vo_dev_select_finish, whose image-only half runs on the ctx's side stream): both against the oracle,
+bit-exact, with other work enqueued between the two calls."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from visual_odometry_amd import _lib, synth
+from visual_odometry_amd._lib import SelOpts, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, torch, img_d, ex, keep, two_calls, min_distance=7.0, between=None):
+    nv, nu = img_d.shape
+    o = SelOpts(float(min_distance), 0.001, 5, int(keep), _lib.SCORER_MINEIGEN, 0.08)
+    eu = torch.from_numpy(ex[:, 0].astype(np.float32)).cuda()
+    ev = torch.from_numpy(ex[:, 1].astype(np.float32)).cuda()
+    ou = torch.zeros(max(keep, 1), dtype=torch.float32, device="cuda"); ov = torch.zeros_like(ou)
+    lin = torch.zeros(max(keep, 1), dtype=torch.int32, device="cuda")
+    met = torch.zeros(max(keep, 1), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    if two_calls:
+        ctx.call("vo_dev_select_begin", ptr(img_d), nu, nv, C.byref(o), len(ex) + 5)
+        if between:
+            between()
+        ctx.call("vo_dev_select_finish", 0, ptr(eu), ptr(ev), len(ex), ptr(ou), ptr(ov), ptr(lin), ptr(met), ptr(cnt))
+    else:
+        ctx.call("vo_dev_select_candidates", ptr(img_d), nu, nv, 0, ptr(eu), ptr(ev), len(ex), C.byref(o), ptr(ou), ptr(ov),
+                 ptr(lin), ptr(met), ptr(cnt))
+    ctx.sync()
+    m = int(cnt.item())
+    return ou[:m].cpu().numpy(), ov[:m].cpu().numpy(), lin[:m].cpu().numpy(), met[:m].cpu().numpy()
+
+
+@pytest.mark.parametrize("shape,n_exist,keep", [((120, 160), 0, 40), ((240, 320), 150, 100), ((376, 1241), 3000, 500)])
+def test_two_call_selection_equals_the_single_call_and_the_oracle(ctx, shape, n_exist, keep):
+    import torch
+    img1, img2, _ = synth.frame_pair(nv=shape[0], nu=shape[1], seed=31, shift=(1.0, 0.5))
+    pu, pv = synth.keypoints(max(n_exist, 1), nv=shape[0], nu=shape[1], seed=32, border=5)
+    ex = np.stack([pu, pv], 1)[:n_exist]
+    img_d = torch.from_numpy(img2).cuda()
+    # other work of the same ctx between the two calls: a pyramid build and a KLT launch on the ctx stream
+    p = torch.from_numpy(np.stack([pu, pv])).cuda()
+    q = torch.zeros_like(p); valid = torch.zeros(p.shape[1], dtype=torch.uint8, device="cuda")
+    score = torch.zeros(p.shape[1], dtype=torch.float32, device="cuda")
+    img1_d = torch.from_numpy(img1).cuda()
+
+    def between():
+        ctx.call("vo_dev_frame_build", 0, ptr(img1_d), shape[1], shape[0], 3)
+        ctx.call("vo_dev_frame_build", 1, ptr(img_d), shape[1], shape[0], 3)
+        ctx.call("vo_dev_klt_track", 0, 1, ptr(p[0]), ptr(p[1]), p.shape[1], 21, 21, 30, C.c_double(0.01), C.c_double(2.0),
+                 ptr(q[0]), ptr(q[1]), ptr(valid), ptr(score), None)
+    one = _run(ctx, torch, img_d, ex, keep, False)
+    two = _run(ctx, torch, img_d, ex, keep, True, between=between)
+    again = _run(ctx, torch, img_d, ex, keep, True)
+    ou, ov, olin, omet = oracle.select_candidates(img2, ex[:, 0].astype(np.float32), ex[:, 1].astype(np.float32), min_distance=7,
+                                                  keep=keep)
+    for got in (one, two, again):
+        assert np.array_equal(got[2], olin) and np.array_equal(got[3], omet)
+        assert np.array_equal(got[0], ou) and np.array_equal(got[1], ov)
+
+
+def test_two_call_selection_misuse_is_an_error(ctx):
+    import torch
+    img = torch.from_numpy(synth.frame_pair(nv=64, nu=80, seed=3)[0]).cuda()
+    o = SelOpts(7.0, 0.001, 5, 10, _lib.SCORER_MINEIGEN, 0.08)
+    out = torch.zeros(16, dtype=torch.float32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    e = torch.zeros(8, dtype=torch.float32, device="cuda")
+    with pytest.raises(_lib.VoError):                                   # finish without begin
+        ctx.call("vo_dev_select_finish", 0, None, None, 0, ptr(out), ptr(out), None, None, ptr(cnt))
+    ctx.call("vo_dev_select_begin", ptr(img), 80, 64, C.byref(o), 4)
+    with pytest.raises(_lib.VoError):                                   # a second begin before the finish
+        ctx.call("vo_dev_select_begin", ptr(img), 80, 64, C.byref(o), 4)
+    with pytest.raises(_lib.VoError):                                   # more existing points than announced
+        ctx.call("vo_dev_select_finish", 0, ptr(e), ptr(e), 8, ptr(out), ptr(out), None, None, ptr(cnt))
+    ctx.call("vo_dev_select_finish", 0, ptr(e), ptr(e), 4, ptr(out), ptr(out), None, None, ptr(cnt))
+    ctx.sync()
+    with pytest.raises(_lib.VoError):
+        ctx.call("vo_dev_select_begin", None, 80, 64, C.byref(o), 4)

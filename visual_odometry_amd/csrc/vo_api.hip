@@ -10,6 +10,13 @@
 // scratch buffer purposes
 enum { SB_PU = 0, SB_PV, SB_QU, SB_QV, SB_VALID, SB_SCORE, SB_IMG, SB_A, SB_B, SB_C, SB_D, SB_E, SB_F, SB_G, SB_H, SB_I };
 
+struct vo_sel_pending {  // vo_dev_select_begin .. vo_dev_select_finish
+    bool open = false;
+    int nu = 0, nv = 0, max_exist = 0;
+    vo_sel_opts o;
+    vo_sel_work w;
+};
+
 const char* vo_strerror(int code) {
     switch (code) {
         case VO_OK: return "ok";
@@ -71,6 +78,13 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    delete c->sel_pending;
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -271,6 +285,22 @@ int vo_klt_track(vo_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int H, i
 }
 
 #include "vo_api_rest.inc"
+
+int vo_int_side_fork(vo_ctx* ctx) {
+    if (!ctx->side) {
+        VO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    VO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    VO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    return VO_OK;
+}
+int vo_int_side_join(vo_ctx* ctx) {
+    VO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+    VO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return VO_OK;
+}
 
 int vo_int_frame_prepare(vo_ctx* ctx, vo_pyr* f, int nu, int nv, int levels) { return frame_prepare(ctx, f, nu, nv, levels); }
 int vo_int_sel_work_prepare(vo_ctx* ctx, int nu, int nv, int keep, int n_exist, double min_distance, vo_sel_work* w) {

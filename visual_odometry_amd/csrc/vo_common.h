@@ -30,11 +30,16 @@ struct vo_buf {            // grow-only device buffer
     size_t cap = 0;
 };
 
+struct vo_sel_pending;
 struct vo_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // side stream for work that depends on the new image only (corner detection) and runs beside tracking
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    struct vo_sel_pending* sel_pending = nullptr;  // vo_dev_select_begin .. vo_dev_select_finish
     vo_pyr frames[VO_NUM_FRAME_SLOTS];
     uint64_t clock = 0;
     unsigned long long* d_counters = nullptr; // VO_COUNTER_SHARDS x 4 u64
@@ -68,8 +73,21 @@ struct vo_sel_work {       // device scratch of the selection pipeline
     int32_t *grid_count, *grid_cursor, *grid_offs, *grid_total; float *grid_su, *grid_sv;
 };
 void vo_select_grid_dims(int nu, int nv, double min_distance, float* cs, int* gu, int* gv);
-int vo_launch_response(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int scorer, int fs, double kappa,
-                       double* d_resp, unsigned long long* d_maxbits);
+int vo_launch_response(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_img, int nu, int nv, int scorer, int fs,
+                       double kappa, double* d_resp, unsigned long long* d_maxbits);
+// selection in two phases: detect needs the image only (response, threshold, regional maxima, corner list);
+// filter needs the existing points (distance filter, selectUniform).  ne_dev (optional): the number of
+// existing points is ne_dev[0] + ne_dev[1] read on the device, n_exist is then only its upper bound.
+int vo_launch_select_detect(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_img, int nu, int nv, const vo_sel_opts* o,
+                            vo_sel_work* w);
+int vo_launch_select_filter(vo_ctx* ctx, hipStream_t stream, int nu, int nv, int u_is_rows, const float* d_eu,
+                            const float* d_ev, int n_exist, const int32_t* ne_dev, const vo_sel_opts* o, vo_sel_work* w,
+                            float* d_out_u, float* d_out_v, int32_t* d_out_lin, double* d_out_metric,
+                            int32_t* d_out_count);
+// side stream: fork = the side stream waits for everything enqueued on the ctx stream so far; join = the ctx
+// stream waits for everything enqueued on the side stream so far
+int vo_int_side_fork(vo_ctx* ctx);
+int vo_int_side_join(vo_ctx* ctx);
 int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is_rows, const float* d_eu,
                      const float* d_ev, int n_exist, const vo_sel_opts* o, vo_sel_work* w, float* d_out_u,
                      float* d_out_v, int32_t* d_out_lin, double* d_out_metric, int32_t* d_out_count);

@@ -336,12 +336,19 @@ void carve(vo_frame_state* st, char* base, size_t* total) {
     st->pos = b.take<int32_t>(pw); st->plist = b.take<int32_t>(cc); st->counts = b.take<int32_t>(16);
     *total = b.off + 256;
 }
-int upload_image(vo_ctx* ctx, vo_frame_state* st, int slot, const uint8_t* img, int on_device) {
+int copy_image(vo_ctx* ctx, vo_frame_state* st, int slot, const uint8_t* img, int on_device) {
     const size_t nb = (size_t)st->nu * st->nv;
     ST_CHECK(hipMemcpyAsync(st->img[slot], img, nb, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    return VO_OK;
+}
+int build_pyramid(vo_ctx* ctx, vo_frame_state* st, int slot) {
     int rc = vo_int_frame_prepare(ctx, &st->pyr[slot], st->nu, st->nv, st->o.klt.levels);
     if (rc) return rc;
     return vo_launch_frame_build(ctx, &st->pyr[slot], st->img[slot]);
+}
+int upload_image(vo_ctx* ctx, vo_frame_state* st, int slot, const uint8_t* img, int on_device) {
+    int rc = copy_image(ctx, st, slot, img, on_device);
+    return rc ? rc : build_pyramid(ctx, st, slot);
 }
 inline int blocks(int n, int b = 256) { return (n + b - 1) / b; }
 } // namespace
@@ -505,7 +512,17 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
     double* pose_now = st->poses + 12 * (size_t)slot;
     const double eps = o.klt.eps > 0 ? o.klt.eps : 0.01;
     int rc;
-    if ((rc = upload_image(ctx, st, b, img, on_device))) return rc;
+    if ((rc = copy_image(ctx, st, b, img, on_device))) return rc;
+    // [5a] :330 the image-only half of the selection (corner response, threshold, regional maxima) starts now on
+    // the ctx's side stream, beside the pyramid build / tracking / pose / triangulation; its other half waits
+    // for it at [5b]
+    vo_sel_work selw;
+    if (o.sel.keep > 0) {
+        if ((rc = vo_int_sel_work_prepare(ctx, st->nu, st->nv, o.sel.keep, cl + cc, o.sel.min_distance, &selw))) return rc;
+        if ((rc = vo_int_side_fork(ctx))) return rc;
+        if ((rc = vo_launch_select_detect(ctx, ctx->side, st->img[b], st->nu, st->nv, &o.sel, &selw))) return rc;
+    }
+    if ((rc = build_pyramid(ctx, st, b))) return rc;
     ST_CHECK(hipMemsetAsync(st->counts, 0, 16 * sizeof(int32_t), sm));
     ST_CHECK(hipMemsetAsync(st->alive, 0, (size_t)pw, sm));
 
@@ -568,16 +585,13 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
     hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, sm, st->alive, pw, nullptr, st->pos, st->counts + 0);
     hipLaunchKernelGGL(k_gather_landmarks, dim3(blocks(pw)), dim3(256), 0, sm, pw, st->alive, st->pos, pw, cl, st->wkp, st->wL, st->wrep,
                        st->kp[n], st->L[n], st->rep[n]);
-    // [5] :330-345 new candidates away from every tracked point
+    // [5b] :330-345 new candidates away from every tracked point; the number of existing points stays on the
+    // device (counts[0] + counts[1]), so the host does not wait here
     hipLaunchKernelGGL(k_existing, dim3(blocks(pw)), dim3(256), 0, sm, st->counts, cl, cc, st->kp[n], st->cu[n], st->eu, st->ev);
-    ST_CHECK(hipMemcpyAsync(st->h_counts, st->counts, 2 * 4, hipMemcpyDeviceToHost, sm));
-    ST_CHECK(hipStreamSynchronize(sm));
-    const int nLn = st->h_counts[0], nCk = st->h_counts[1];
     if (o.sel.keep > 0) {
-        vo_sel_work w;
-        if ((rc = vo_int_sel_work_prepare(ctx, st->nu, st->nv, o.sel.keep, nLn + nCk, o.sel.min_distance, &w))) return rc;
-        if ((rc = vo_launch_select(ctx, st->img[b], st->nu, st->nv, 0, st->eu, st->ev, nLn + nCk, &o.sel, &w, st->su, st->sv, st->slin,
-                                   nullptr, st->counts + 2))) return rc;
+        if ((rc = vo_int_side_join(ctx))) return rc;
+        if ((rc = vo_launch_select_filter(ctx, sm, st->nu, st->nv, 0, st->eu, st->ev, cl + cc, st->counts, &o.sel, &selw, st->su, st->sv,
+                                          st->slin, nullptr, st->counts + 2))) return rc;
     }
     hipLaunchKernelGGL(k_append_new, dim3(blocks(std::max(o.sel.keep, 1))), dim3(256), 0, sm, st->counts, cc, st->su, st->sv, slot,
                        st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]);

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int32_t* __restrict_
 // only moves them towards the cells that must see them.  The verdict is an "any", hence independent
 // of the (atomic) order inside a cell: bit-exact against the oracle's all-pairs loop.
 struct GridArgs {
-    const float *eu, *ev; int ne; float inv_cs; int gu, gv;
+    const float *eu, *ev; int ne; const int32_t* ne_dev; float inv_cs; int gu, gv;
     int32_t *count, *offs, *cursor; float *su, *sv;
 };
 __device__ __forceinline__ int grid_cell1(float x, float inv_cs, int g) {
@@ -237,13 +237,13 @@ __device__ __forceinline__ int grid_cell1(float x, float inv_cs, int g) {
 }
 __global__ __launch_bounds__(256) void k_grid_count(GridArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.ne) return;
+    if (i >= (a.ne_dev ? a.ne_dev[0] + a.ne_dev[1] : a.ne)) return;
     const int c = grid_cell1(a.ev[i], a.inv_cs, a.gv) * a.gu + grid_cell1(a.eu[i], a.inv_cs, a.gu);
     atomicAdd(&a.count[c], 1);
 }
 __global__ __launch_bounds__(256) void k_grid_fill(GridArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.ne) return;
+    if (i >= (a.ne_dev ? a.ne_dev[0] + a.ne_dev[1] : a.ne)) return;
     const float u = a.eu[i], v = a.ev[i];
     const int c = grid_cell1(v, a.inv_cs, a.gv) * a.gu + grid_cell1(u, a.inv_cs, a.gu);
     const int pos = a.offs[c] + atomicAdd(&a.cursor[c], 1);
@@ -574,8 +574,8 @@ static void gauss_weights_host(int fs, int32_t* w) { // N6, identical to oracle/
     for (int k = 0; k < fs; ++k) w[k] = (int32_t)lround(4096.0 * g[k] / sum);
 }
 
-int vo_launch_response(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int scorer, int fs, double kappa,
-                       double* d_resp, unsigned long long* d_maxbits) {
+int vo_launch_response(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_img, int nu, int nv, int scorer, int fs,
+                       double kappa, double* d_resp, unsigned long long* d_maxbits) {
     if (fs < 1 || fs > 15 || !(fs & 1)) { ctx->last_error = "select: filter_size must be odd in [1,15]"; return VO_ERR_BAD_ARG; }
     if (scorer != VO_SCORER_MINEIGEN && scorer != VO_SCORER_HARRIS) { ctx->last_error = "select: unknown scorer"; return VO_ERR_BAD_ARG; }
     if (nu < 3 || nv < 3) { ctx->last_error = "select: image smaller than 3x3"; return VO_ERR_BAD_ARG; }
@@ -587,14 +587,14 @@ int vo_launch_response(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int sc
     const int r = a.r;
     const int SW = RS_TU + 2 * r + 2, SH = RS_TV + 2 * r + 2, PW = RS_TU + 2 * r, PH = RS_TV + 2 * r;
     size_t lds = ((size_t)(SW * SH + 15) & ~(size_t)15) + sizeof(int32_t) * (3 * (size_t)PW * PH + 3 * (size_t)RS_TU * PH);
-    if (d_maxbits) VO_HIP_CHECK(ctx, hipMemsetAsync(d_maxbits, 0, sizeof(unsigned long long), ctx->stream));
+    if (d_maxbits) VO_HIP_CHECK(ctx, hipMemsetAsync(d_maxbits, 0, sizeof(unsigned long long), stream));
     dim3 grid((nu + RS_TU - 1) / RS_TU, (nv + RS_TV - 1) / RS_TV);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_response, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_response, grid, dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(k_response, grid, dim3(256), lds, stream, a);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }
@@ -616,45 +616,62 @@ void vo_select_grid_dims(int nu, int nv, double min_distance, float* cs, int* gu
     *cs = c; *gu = (int)(nu / c) + 2; *gv = (int)(nv / c) + 2;
 }
 
-int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is_rows, const float* d_eu,
-                     const float* d_ev, int n_exist, const vo_sel_opts* o, vo_sel_work* w, float* d_out_u,
-                     float* d_out_v, int32_t* d_out_lin, double* d_out_metric, int32_t* d_out_count) {
-    if (o->keep < 0 || n_exist < 0) { ctx->last_error = "select: negative count"; return VO_ERR_BAD_ARG; }
-    int rc = vo_launch_response(ctx, d_img, nu, nv, o->scorer, o->filter_size, o->kappa, w->resp, w->maxbits);
+int vo_launch_select_detect(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_img, int nu, int nv, const vo_sel_opts* o,
+                            vo_sel_work* w) {
+    if (o->keep < 0) { ctx->last_error = "select: negative count"; return VO_ERR_BAD_ARG; }
+    int rc = vo_launch_response(ctx, stream, d_img, nu, nv, o->scorer, o->filter_size, o->kappa, w->resp, w->maxbits);
     if (rc) return rc;
     const long n = (long)nu * nv;
     const int nblk = (int)((n + DT_BLOCK - 1) / DT_BLOCK);
     if (nblk > w->nblk) { ctx->last_error = "select: scratch too small"; return VO_ERR_BAD_ARG; }
-    hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, ctx->stream, w->resp, nu, nv, w->maxbits,
+    hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, stream, w->resp, nu, nv, w->maxbits,
                        o->min_quality, 0, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, w->blk_counts, nblk, w->blk_offs, w->m0, w->cap);
-    hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, ctx->stream, w->resp, nu, nv, w->maxbits,
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, w->blk_counts, nblk, w->blk_offs, w->m0, w->cap);
+    hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, stream, w->resp, nu, nv, w->maxbits,
                        o->min_quality, 1, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric);
+    VO_HIP_CHECK(ctx, hipMemsetAsync(w->m0 + 1, 0, sizeof(int32_t), stream)); // number of kept corners
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}
+
+int vo_launch_select_filter(vo_ctx* ctx, hipStream_t stream, int nu, int nv, int u_is_rows, const float* d_eu,
+                            const float* d_ev, int n_exist, const int32_t* ne_dev, const vo_sel_opts* o, vo_sel_work* w,
+                            float* d_out_u, float* d_out_v, int32_t* d_out_lin, double* d_out_metric,
+                            int32_t* d_out_count) {
+    if (o->keep < 0 || n_exist < 0) { ctx->last_error = "select: negative count"; return VO_ERR_BAD_ARG; }
     const int dblk = (w->cap + 255) / 256;
-    VO_HIP_CHECK(ctx, hipMemsetAsync(w->m0 + 1, 0, sizeof(int32_t), ctx->stream)); // number of kept corners
     const float thr_d2 = d2_threshold((float)o->min_distance);
     if (n_exist == 0 || !(thr_d2 > 0.0f)) {
-        hipLaunchKernelGGL(k_keep_all, dim3(dblk), dim3(256), 0, ctx->stream, w->m0, w->keep, w->klist, w->m0 + 1);
+        hipLaunchKernelGGL(k_keep_all, dim3(dblk), dim3(256), 0, stream, w->m0, w->keep, w->klist, w->m0 + 1);
     } else {
         GridArgs g;
-        g.eu = d_eu; g.ev = d_ev; g.ne = n_exist; g.inv_cs = 1.0f / w->grid_cs; g.gu = w->grid_gu; g.gv = w->grid_gv;
+        g.eu = d_eu; g.ev = d_ev; g.ne = n_exist; g.ne_dev = ne_dev; g.inv_cs = 1.0f / w->grid_cs; g.gu = w->grid_gu; g.gv = w->grid_gv;
         g.count = w->grid_count; g.offs = w->grid_offs; g.cursor = w->grid_cursor; g.su = w->grid_su; g.sv = w->grid_sv;
         const int ncell = g.gu * g.gv;
-        VO_HIP_CHECK(ctx, hipMemsetAsync(g.count, 0, sizeof(int32_t) * 2 * (size_t)ncell, ctx->stream)); // count + cursor
+        VO_HIP_CHECK(ctx, hipMemsetAsync(g.count, 0, sizeof(int32_t) * 2 * (size_t)ncell, stream)); // count + cursor
         const int eblk = (n_exist + 255) / 256;
-        hipLaunchKernelGGL(k_grid_count, dim3(eblk), dim3(256), 0, ctx->stream, g);
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, g.count, ncell, g.offs, w->grid_total, 0x7fffffff);
-        hipLaunchKernelGGL(k_grid_fill, dim3(eblk), dim3(256), 0, ctx->stream, g);
-        hipLaunchKernelGGL(k_distance, dim3(dblk), dim3(256), 0, ctx->stream, w->lu, w->lv, w->m0, g, thr_d2, w->keep, w->klist, w->m0 + 1);
+        hipLaunchKernelGGL(k_grid_count, dim3(eblk), dim3(256), 0, stream, g);
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, g.count, ncell, g.offs, w->grid_total, 0x7fffffff);
+        hipLaunchKernelGGL(k_grid_fill, dim3(eblk), dim3(256), 0, stream, g);
+        hipLaunchKernelGGL(k_distance, dim3(dblk), dim3(256), 0, stream, w->lu, w->lv, w->m0, g, thr_d2, w->keep, w->klist, w->m0 + 1);
     }
     UniArgs a;
     a.cu = w->lu; a.cv = w->lv; a.metric = w->metric; a.lin = w->lin; a.keep = w->keep; a.sel = w->sel; a.m0 = w->m0; a.nkeep = w->m0 + 1;
     a.n_keep = o->keep; a.nu = nu; a.nv = nv; a.u_is_rows = u_is_rows;
     a.cell_key = w->cell_key; a.cell_idx = w->cell_idx; a.klist = w->klist; a.kcell = w->kcell;
     a.out_u = d_out_u; a.out_v = d_out_v; a.out_lin = d_out_lin; a.out_metric = d_out_metric; a.out_count = d_out_count;
-    hipLaunchKernelGGL(k_uniform, dim3(1), dim3(1024), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_uniform, dim3(1), dim3(1024), 0, stream, a);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
+}
+
+int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is_rows, const float* d_eu,
+                     const float* d_ev, int n_exist, const vo_sel_opts* o, vo_sel_work* w, float* d_out_u,
+                     float* d_out_v, int32_t* d_out_lin, double* d_out_metric, int32_t* d_out_count) {
+    int rc = vo_launch_select_detect(ctx, ctx->stream, d_img, nu, nv, o, w);
+    if (rc) return rc;
+    return vo_launch_select_filter(ctx, ctx->stream, nu, nv, u_is_rows, d_eu, d_ev, n_exist, nullptr, o, w, d_out_u, d_out_v,
+                                   d_out_lin, d_out_metric, d_out_count);
 }
 
 int vo_greedy_num_blocks(long n) { return (int)((n + (long)GR_BLOCK * GR_PER - 1) / ((long)GR_BLOCK * GR_PER)); }

@@ -107,17 +107,26 @@ class FrameWorkload:
                       _p(self.ex[1]), self.n_exist, C.byref(self.sel_opts), _p(self.sel_u), _p(self.sel_v),
                       _p(self.sel_lin), None, _p(self.sel_cnt))
 
+    def select_begin(self, frame):
+        """The image-only half of the selection, on the ctx's side stream beside what is enqueued next."""
+        self.ctx.call("vo_dev_select_begin", _p(self.frames[frame]), self.nu, self.nv, C.byref(self.sel_opts), self.n_exist)
+
+    def select_finish(self):
+        self.ctx.call("vo_dev_select_finish", 0, _p(self.ex[0]), _p(self.ex[1]), self.n_exist, _p(self.sel_u), _p(self.sel_v),
+                      _p(self.sel_lin), None, _p(self.sel_cnt))
+
     def step(self):
         """frame k (slot k%2, already built) -> frame k+1."""
         k = self.k
         a, b = k % 2, (k + 1) % 2
         nxt = (k % self.n_frames) + 1
+        self.select_begin(nxt)     # corner detection on the new image runs beside the pyramid build and tracking
         self.build(b, nxt)
         self.track_all(a, b)       # landmarks + candidates in one launch
         if self.nl >= 4:
             self.pose()
         self.triangulate()
-        self.select(nxt)
+        self.select_finish()       # distance filter against the existing points + selectUniform
         self.k += 1
         if self.k % self.n_frames == 0:       # loop the sequence: rebuild frame 0 as "previous"
             self.build(self.k % 2, 0)
