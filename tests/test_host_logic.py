@@ -108,3 +108,32 @@ def test_klt_tracker_option_checks():
 def test_camera_params_hold_the_transposed_intrinsics():
     cp = modules.CameraParams(K)
     np.testing.assert_array_equal(cp.IntrinsicMatrix, K.T)   # utils/dataLoaderKitti.m:50-53
+
+
+def test_merge_policy_closed_form_equals_the_sequential_loop():
+    """The device merge for the usual sizes (k_merge_par, vo_frame.hip) does not walk the candidates one by one as
+    modules/VisualOdometry.m:87-127 does; it uses two all-pairs counts.  Their equivalence to the sequential policy
+    (first maximum evicted when the candidate's error is not larger, appended when below the cap), survivors'
+    identity and order included, on random pools with many ties."""
+    rng = np.random.default_rng(0)
+
+    def sequential(init, cand, cap):
+        vals = list(init); ids = [("L", i) for i in range(len(init))]; acc = []
+        for j, r in enumerate(cand):
+            mi, mx = (int(np.argmax(vals)), max(vals)) if vals else (-1, -np.inf)       # :89-90
+            if len(vals) >= cap and r <= mx:                                            # :116-122
+                del vals[mi]; del ids[mi]
+            if len(vals) < cap:                                                         # :123-127
+                vals.append(r); ids.append(("C", j)); acc.append(j)
+        return ids, acc
+
+    def closed(init, cand, cap):
+        n0 = len(init); pool = np.concatenate([init, cand]).astype(float); order = np.arange(len(pool))
+        rank = (pool[None, :] < pool[:, None]).sum(1) + ((pool[None, :] == pool[:, None]) & (order[None, :] > order[:, None])).sum(1)
+        acc = [j for j in range(len(cand)) if (pool[:n0 + j] < cand[j]).sum() < cap]
+        surv = rank < cap
+        return [("L", i) for i in range(n0) if surv[i]] + [("C", j) for j in acc if surv[n0 + j]], acc
+    for _ in range(1500):
+        cap = int(rng.integers(1, 14)); n0 = min(int(rng.integers(0, 12)), cap); q = int(rng.integers(1, 6))
+        init = rng.integers(0, q, n0) / 2.0; cand = rng.integers(0, q, int(rng.integers(0, 15))) / 2.0
+        assert sequential(init, cand, cap) == closed(init, cand, cap)

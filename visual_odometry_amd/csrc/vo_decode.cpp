@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 
 #include "../../include/vo_hip.h"
 
@@ -48,7 +49,7 @@ int png_header(const uint8_t* d, size_t n, ImgHdr* h, std::string* err) {
     h->bit_depth = p[8];
     h->color_type = p[9];
     h->interlace = p[12];
-    if (W == 0 || H == 0 || W > 65535u || H > 65535u) {
+    if (W == 0 || H == 0 || W > 65535u || H > 65535u || (uint64_t)W * H > VO_DEC_MAX_PIXELS) {
         *err = "png: image size out of range";
         return VO_ERR_BAD_ARG;
     }
@@ -103,7 +104,7 @@ int pnm_header(const uint8_t* d, size_t n, ImgHdr* h, std::string* err) {
         *err = "pnm: malformed header";
         return VO_ERR_BAD_ARG;
     }
-    if (W <= 0 || H <= 0 || W > 65535 || H > 65535 || mv <= 0 || mv > 65535) {
+    if (W <= 0 || H <= 0 || W > 65535 || H > 65535 || (uint64_t)W * H > VO_DEC_MAX_PIXELS || mv <= 0 || mv > 65535) {
         *err = "pnm: size or maxval out of range";
         return VO_ERR_BAD_ARG;
     }
@@ -129,6 +130,10 @@ int image_header(const uint8_t* d, size_t n, ImgHdr* h, std::string* err) {
         const int rc = vo_jpeg_header(d, n, &h->W, &h->H, &h->channels, err);
         h->bit_depth = 8;
         h->kind = 3;
+        if (rc == VO_OK && (uint64_t)h->W * h->H > VO_DEC_MAX_PIXELS) {
+            *err = "jpeg: image size out of range";
+            return VO_ERR_BAD_ARG;
+        }
         return rc;
     }
     *err = "unknown image format (PNG, baseline JPEG and binary PGM/PPM are decoded)";
@@ -387,8 +392,18 @@ int read_file(const char* path, std::vector<uint8_t>* buf, size_t* n, std::strin
 
 int vo_dec_header(const uint8_t* d, size_t n, ImgHdr* h, std::string* err) { return image_header(d, n, h, err); }
 int vo_dec_decode(const uint8_t* d, size_t n, const ImgHdr& h, uint8_t* out, DecodeScratch* sc, std::string* err) {
-    return image_decode(d, n, h, out, sc, err);
+    try {
+        return image_decode(d, n, h, out, sc, err);
+    } catch (const std::bad_alloc&) {  // scratch vectors: nothing crosses the C ABI as an exception
+        *err = "out of host memory while decoding";
+        return VO_ERR_OOM;
+    }
 }
 int vo_dec_read_file(const char* path, std::vector<uint8_t>* buf, size_t* n, std::string* err) {
-    return read_file(path, buf, n, err);
+    try {
+        return read_file(path, buf, n, err);
+    } catch (const std::bad_alloc&) {
+        *err = "out of host memory while reading";
+        return VO_ERR_OOM;
+    }
 }

@@ -6,6 +6,9 @@
 #include <string>
 #include <vector>
 
+// larger headers are refused before anything is allocated for them (2^27 pixels = 11585 x 11585)
+constexpr uint64_t VO_DEC_MAX_PIXELS = 1ull << 27;
+
 struct ImgHdr {
     int H = 0, W = 0;
     int channels = 0;   // of the decoded output: 1 or 3

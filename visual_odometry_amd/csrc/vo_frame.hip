@@ -225,6 +225,88 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
     if (lane == 0) *a.n_promoted = prom;
 }
 
+// The same policy without the sequential loop.  At the cap every accepted candidate evicts the current
+// first maximum, so the landmark set is a streaming "cap smallest so far": the maximum never grows, an
+// element below the final maximum T is never evicted, one above T never survives, and among elements equal
+// to T the ones latest in order survive (eviction takes the first maximum; accepted candidates are appended
+// behind everything).  Order = work-array order: surviving landmarks, then candidates in candidate order.
+//   accepted(j)  <=>  #{x before j in order : v_x < r_j} < cap            (what :116-127 decides at j's turn)
+//   survives(e)  <=>  #{x : v_x < v_e} + #{x : v_x = v_e, x after e} < cap
+// Both are all-pairs counts over the pool (landmarks + promotable candidates): one block, every thread
+// owns elements and walks the pool in LDS (broadcast reads).  Identical to k_merge (tests/test_gpu_frame.py
+// runs both; the equivalence is also checked on tie-heavy random pools in tests/test_host_logic.py).
+__device__ __forceinline__ int block_excl_scan_1024(int flag, int* total, int* s_w) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int within = __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();                       // s_w may still be read from the previous call
+    if (lane == 0) s_w[w] = __popcll(bal);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = s_w[k];
+        if (k < w) base += c;
+        tot += c;
+    }
+    *total = tot;
+    return base + within;
+}
+
+__global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a) {
+    __shared__ double s_v[MERGE_LDS];
+    __shared__ int32_t s_pidx[MERGE_LDS];
+    __shared__ uint8_t s_acc[MERGE_LDS], s_surv[MERGE_LDS];
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x;
+    const int n0 = *a.n0;
+    // ordered list of the promotable candidates
+    int np = 0;
+    for (int i0 = 0; i0 < a.nC; i0 += 1024) {
+        const int i = i0 + tid;
+        const int f = (i < a.nC && a.cls[i] == 1) ? 1 : 0;
+        int tot;
+        const int pos = block_excl_scan_1024(f, &tot, s_w);
+        if (f) s_pidx[np + pos] = i;
+        np += tot;
+    }
+    __syncthreads();
+    const int P = n0 + np;                 // <= PW <= MERGE_LDS (checked by the host)
+    for (int e = tid; e < P; e += 1024) s_v[e] = e < n0 ? a.wrep[e] : a.crep[s_pidx[e - n0]];
+    __syncthreads();
+    for (int e = tid; e < P; e += 1024) {
+        const double ve = s_v[e];
+        int rank = 0, before = 0;
+        for (int x = 0; x < P; ++x) {
+            const double vx = s_v[x];
+            const int less = vx < ve;
+            rank += less | ((vx == ve) & (x > e));
+            before += less & (x < e);
+        }
+        s_surv[e] = rank < a.cap;
+        s_acc[e] = before < a.cap;         // meaningful for candidates (e >= n0)
+    }
+    __syncthreads();
+    // accepted candidates, in order, become work-array entries n0, n0 + 1, ...
+    int prom = 0;
+    for (int j0 = 0; j0 < np; j0 += 1024) {
+        const int j = j0 + tid;
+        const int f = (j < np && s_acc[n0 + j]) ? 1 : 0;
+        int tot;
+        const int pos = block_excl_scan_1024(f, &tot, s_w);
+        if (f) {
+            const int i = s_pidx[j], d = n0 + prom + pos;
+            a.wL[d] = a.X[i]; a.wL[a.PW + d] = a.X[a.capC + i]; a.wL[2 * a.PW + d] = a.X[2 * a.capC + i];
+            a.wkp[d] = a.cq[i]; a.wkp[a.PW + d] = a.cq[a.capC + i];
+            a.wrep[d] = s_v[n0 + j];
+            a.alive[d] = s_surv[n0 + j];
+        }
+        prom += tot;
+    }
+    for (int i = tid; i < n0; i += 1024) a.alive[i] = s_surv[i];
+    if (tid == 0) *a.n_promoted = prom;
+}
+
 // ordered compaction of the live landmarks into the next state (pitch capL)
 __global__ void k_gather_landmarks(int n, const uint8_t* alive, const int32_t* pos, int PW, int capL, const double* wkp,
                                    const double* wL, const double* wrep, double* kp, double* L, double* rep) {
@@ -577,7 +659,8 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
         m.nC = nC; m.cap = cl; m.PW = pw; m.capC = cc; m.cls = st->cls; m.X = st->X; m.crep = st->crep; m.cq = st->cq;
         m.wkp = st->wkp; m.wL = st->wL; m.wrep = st->wrep; m.alive = st->alive; m.n0 = st->counts + 7; m.plist = st->plist;
         m.n_promoted = st->counts + 8;
-        hipLaunchKernelGGL(k_merge, dim3(1), dim3(64), 0, sm, m);
+        if (pw <= MERGE_LDS) hipLaunchKernelGGL(k_merge_par, dim3(1), dim3(1024), 0, sm, m);   // the usual sizes
+        else hipLaunchKernelGGL(k_merge, dim3(1), dim3(64), 0, sm, m);                          // sequential, any size
         hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, sm, st->keepf, nC, nullptr, st->pos, st->counts + 1);
         hipLaunchKernelGGL(k_gather_candidates, dim3(blocks(nC)), dim3(256), 0, sm, nC, st->keepf, st->pos, cc, st->cq, st->cf[s],
                            st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]);

@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -453,8 +454,14 @@ int vo_ingest_open(vo_ctx* ctx, const char* const* paths, int n_paths, const vo_
     if (!g) return VO_ERR_OOM;
     g->ctx = ctx;
     g->to_gray = opts ? (opts->keep_rgb ? 0 : 1) : 1;
-    for (int i = 0; i < n_paths; ++i) g->paths.emplace_back(paths[i] ? paths[i] : "");
-    g->slots.resize(depth);
+    try {
+        for (int i = 0; i < n_paths; ++i) g->paths.emplace_back(paths[i] ? paths[i] : "");
+        g->slots.resize(depth);
+    } catch (const std::exception&) {
+        delete g;
+        ctx->last_error = "vo_ingest_open: out of host memory";
+        return VO_ERR_OOM;
+    }
     hipError_t e = hipStreamCreateWithFlags(&g->copy, hipStreamNonBlocking);
     for (auto& s : g->slots) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ready, hipEventDisableTiming);
@@ -468,7 +475,15 @@ int vo_ingest_open(vo_ctx* ctx, const char* const* paths, int n_paths, const vo_
         return VO_ERR_HIP;
     }
     if ((long)threads > (long)n_paths) threads = n_paths > 0 ? n_paths : 1;
-    for (int t = 0; t < threads; ++t) g->workers.emplace_back(ingest_worker, g);
+    try {
+        for (int t = 0; t < threads; ++t) g->workers.emplace_back(ingest_worker, g);
+    } catch (const std::exception&) {  // no more threads to be had: run with the ones that started, if any
+        if (g->workers.empty()) {
+            ctx->last_error = "vo_ingest_open: cannot start a decode thread";
+            vo_ingest_close(g);
+            return VO_ERR_OOM;
+        }
+    }
     *out = g;
     return VO_OK;
 }
