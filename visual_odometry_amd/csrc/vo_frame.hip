@@ -13,31 +13,99 @@
 
 namespace {
 
-// ---- ordered compaction: pos[i] = number of set flags before i; *count = total.  One block. ----
-__global__ __launch_bounds__(1024) void k_scan_flags(const uint8_t* __restrict__ flag, int n, const int* d_n,
-                                                     int32_t* __restrict__ pos, int32_t* count) {
-    __shared__ int wsum[16];
-    __shared__ int base_s;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (d_n) n = min(n, *d_n);
-    if (tid == 0) base_s = 0;
+// exclusive position of every set flag among the block's 1024 threads, and their total
+__device__ __forceinline__ int block_excl_scan_1024(int flag, int* total, int* s_w) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const int within = __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();                       // s_w may still be read from the previous call
+    if (lane == 0) s_w[w] = __popcll(bal);
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 1024) {
-        const int i = i0 + tid;
-        const int f = (i < n && flag[i]) ? 1 : 0;
-        const unsigned long long bal = __ballot(f);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wid] = __popcll(bal);
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) { if (w < wid) woff += wsum[w]; tot += wsum[w]; }
-        const int base = base_s;
-        if (i < n) pos[i] = base + woff + before;
-        __syncthreads();
-        if (tid == 0) base_s = base + tot;
-        __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = s_w[k];
+        if (k < w) base += c;
+        tot += c;
     }
-    if (tid == 0) *count = base_s;
+    *total = tot;
+    return base + within;
+}
+
+// ordered compaction in one launch: Op::flag(i) says whether element i stays, Op::move(i, d) puts it at
+// position d of the output; *count = number kept.  One block walks the n elements 1024 at a time.
+template <class Op>
+__global__ __launch_bounds__(1024) void k_compact(Op op, int n, int32_t* count) {
+    __shared__ int s_w[16];
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + (int)threadIdx.x;
+        const int f = (i < n && op.flag(i)) ? 1 : 0;
+        int tot;
+        const int pos = block_excl_scan_1024(f, &tot, s_w);
+        if (f) op.move(i, base + pos);
+        base += tot;
+    }
+    if (threadIdx.x == 0 && count) *count = base;
+}
+
+// landmarks whose keypoint tracked validly (:280-281): (q, L) -> (vk, vl), pitch = capL
+struct TrackedOp {
+    const uint8_t* valid; const double *qu, *qv, *L; int capL; double *vk, *vl;
+    __device__ bool flag(int i) const { return valid[i] != 0; }
+    __device__ void move(int i, int d) const {
+        vk[d] = qu[i]; vk[capL + d] = qv[i];
+        vl[d] = L[i]; vl[capL + d] = L[capL + i]; vl[2 * capL + d] = L[2 * capL + i];
+    }
+};
+// :302 strict <, :308-315 survivors into the merge work arrays (pitch PW), alive = 1
+struct KeptOp {
+    const double* err; double thr; const double *vk, *vl; int capL, PW; double *wkp, *wL, *wrep; uint8_t* alive;
+    __device__ bool flag(int i) const { return err[i] < thr; }
+    __device__ void move(int i, int d) const {
+        wkp[d] = vk[i]; wkp[PW + d] = vk[capL + i];
+        wL[d] = vl[i]; wL[PW + d] = vl[capL + i]; wL[2 * PW + d] = vl[2 * capL + i];
+        wrep[d] = err[i];
+        alive[d] = 1;
+    }
+};
+// :106-113, :130: 0 drop, 1 promote (angle large), 2 keep as candidate (angle small, young enough)
+struct ClassifyArgs {
+    const uint8_t *tracked, *ok; const double *rep, *ang; const int32_t* ctime; double max_rep, ang_thr; int recall;
+    __device__ int cls(int i) const {
+        if (tracked[i] && ok[i] && rep[i] <= max_rep) {
+            if (ang[i] > ang_thr) return 1;
+            if (ctime[i] > -recall) return 2;
+        }
+        return 0;
+    }
+};
+// :130-139 kept candidates, aged by one frame
+struct CandOp {
+    ClassifyArgs c; int capC; const double *cq, *cf; const int32_t *cpose, *ctime; double *ncu, *ncf; int32_t *ncpose, *nctime;
+    __device__ bool flag(int i) const { return c.cls(i) == 2; }
+    __device__ void move(int i, int d) const {
+        ncu[d] = cq[i]; ncu[capC + d] = cq[capC + i];
+        ncf[d] = cf[i]; ncf[capC + d] = cf[capC + i];
+        ncpose[d] = cpose[i]; nctime[d] = ctime[i] - 1;
+    }
+};
+// the live landmarks, in order, into the next state (pitch capL)
+struct LandmarkOp {
+    const uint8_t* alive; int PW, capL; const double *wkp, *wL, *wrep; double *kp, *L, *rep;
+    __device__ bool flag(int i) const { return alive[i] != 0; }
+    __device__ void move(int i, int d) const {
+        if (d >= capL) return;
+        kp[d] = wkp[i]; kp[capL + d] = wkp[PW + i];
+        L[d] = wL[i]; L[capL + d] = wL[PW + i]; L[2 * capL + d] = wL[2 * PW + i];
+        rep[d] = wrep[i];
+    }
+};
+// start of a frame: the per-frame counters and the tombstone array
+__global__ void k_frame_reset(int32_t* counts, uint8_t* alive, int pw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 16) counts[i] = 0;
+    if (i < pw) alive[i] = 0;
 }
 
 // the frame's two track calls (:278 landmarks, :71 candidates) share the image pair: one launch
@@ -51,34 +119,6 @@ __global__ void k_split_candidates(int nL, int nC, int capC, int PW, const doubl
     if (c >= nC) return;
     cq[c] = q[nL + c]; cq[capC + c] = q[PW + nL + c];
     cvalid[c] = valid[nL + c];
-}
-
-// landmarks whose keypoint tracked validly (:280-281): (q, L) -> (vk, vl), pitch = capL
-__global__ void k_gather_tracked(int n, const uint8_t* valid, const int32_t* pos, const double* qu, const double* qv,
-                                 const double* L, int capL, double* vk, double* vl) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !valid[i]) return;
-    const int d = pos[i];
-    vk[d] = qu[i]; vk[capL + d] = qv[i];
-    vl[d] = L[i]; vl[capL + d] = L[capL + i]; vl[2 * capL + d] = L[2 * capL + i];
-}
-
-// :302 strict <
-__global__ void k_flag_less(const double* err, int n, double thr, uint8_t* flag) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = err[i] < thr ? 1 : 0;
-}
-
-// :308-315 into the merge work arrays (pitch PW), alive = 1
-__global__ void k_gather_kept(int n, const uint8_t* flag, const int32_t* pos, const double* vk, const double* vl,
-                              const double* err, int capL, int PW, double* wkp, double* wL, double* wrep, uint8_t* alive) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !flag[i]) return;
-    const int d = pos[i];
-    wkp[d] = vk[i]; wkp[PW + d] = vk[capL + i];
-    wL[d] = vl[i]; wL[PW + d] = vl[capL + i]; wL[2 * PW + d] = vl[2 * capL + i];
-    wrep[d] = err[i];
-    alive[d] = 1;
 }
 
 // pose [R_WC; t_WC] (:318) from the RANSAC record R_cw, t_cw: C = -R_cw^T t_cw
@@ -120,6 +160,7 @@ struct MergeArgs {
     const int32_t* n0;              // landmarks that survived the reprojection filter
     int32_t* plist;                 // scratch, nC
     int32_t* n_promoted;
+    ClassifyArgs c;                 // k_merge_par classifies inline; k_merge reads cls
 };
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ unsigned dpp_u32(unsigned x) {
@@ -235,24 +276,6 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
 // Both are all-pairs counts over the pool (landmarks + promotable candidates): one block, every thread
 // owns elements and walks the pool in LDS (broadcast reads).  Identical to k_merge (tests/test_gpu_frame.py
 // runs both; the equivalence is also checked on tie-heavy random pools in tests/test_host_logic.py).
-__device__ __forceinline__ int block_excl_scan_1024(int flag, int* total, int* s_w) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const unsigned long long bal = __ballot(flag);
-    const int within = __popcll(bal & ((1ull << lane) - 1ull));
-    __syncthreads();                       // s_w may still be read from the previous call
-    if (lane == 0) s_w[w] = __popcll(bal);
-    __syncthreads();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int c = s_w[k];
-        if (k < w) base += c;
-        tot += c;
-    }
-    *total = tot;
-    return base + within;
-}
-
 __global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a) {
     __shared__ double s_v[MERGE_LDS];
     __shared__ int32_t s_pidx[MERGE_LDS];
@@ -264,7 +287,7 @@ __global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a) {
     int np = 0;
     for (int i0 = 0; i0 < a.nC; i0 += 1024) {
         const int i = i0 + tid;
-        const int f = (i < a.nC && a.cls[i] == 1) ? 1 : 0;
+        const int f = (i < a.nC && a.c.cls(i) == 1) ? 1 : 0;
         int tot;
         const int pos = block_excl_scan_1024(f, &tot, s_w);
         if (f) s_pidx[np + pos] = i;
@@ -305,30 +328,6 @@ __global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a) {
     }
     for (int i = tid; i < n0; i += 1024) a.alive[i] = s_surv[i];
     if (tid == 0) *a.n_promoted = prom;
-}
-
-// ordered compaction of the live landmarks into the next state (pitch capL)
-__global__ void k_gather_landmarks(int n, const uint8_t* alive, const int32_t* pos, int PW, int capL, const double* wkp,
-                                   const double* wL, const double* wrep, double* kp, double* L, double* rep) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !alive[i]) return;
-    const int d = pos[i];
-    if (d >= capL) return;
-    kp[d] = wkp[i]; kp[capL + d] = wkp[PW + i];
-    L[d] = wL[i]; L[capL + d] = wL[PW + i]; L[2 * capL + d] = wL[2 * PW + i];
-    rep[d] = wrep[i];
-}
-
-// :130-139 kept candidates, aged by one frame
-__global__ void k_gather_candidates(int n, const uint8_t* keepf, const int32_t* pos, int capC, const double* cq,
-                                    const double* cf, const int32_t* cpose, const int32_t* ctime, double* ncu, double* ncf,
-                                    int32_t* ncpose, int32_t* nctime) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !keepf[i]) return;
-    const int d = pos[i];
-    ncu[d] = cq[i]; ncu[capC + d] = cq[capC + i];
-    ncf[d] = cf[i]; ncf[capC + d] = cf[capC + i];
-    ncpose[d] = cpose[i]; nctime[d] = ctime[i] - 1;
 }
 
 // :330-331 [keypoints; candidate_keypoints] cast to single
@@ -605,8 +604,7 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
         if ((rc = vo_launch_select_detect(ctx, ctx->side, st->img[b], st->nu, st->nv, &o.sel, &selw))) return rc;
     }
     if ((rc = build_pyramid(ctx, st, b))) return rc;
-    ST_CHECK(hipMemsetAsync(st->counts, 0, 16 * sizeof(int32_t), sm));
-    ST_CHECK(hipMemsetAsync(st->alive, 0, (size_t)pw, sm));
+    hipLaunchKernelGGL(k_frame_reset, dim3(blocks(std::max(pw, 16))), dim3(256), 0, sm, st->counts, st->alive, pw);
 
     // [1] :278-281 and :71 track the landmarks' keypoints and the candidates in one launch; keep the
     // validly tracked landmarks in order
@@ -617,8 +615,8 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
                                 o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, st->score, nullptr))) return rc;
     }
     if (nL > 0) {
-        hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, sm, st->valid, nL, nullptr, st->pos, st->counts + 6);
-        hipLaunchKernelGGL(k_gather_tracked, dim3(blocks(nL)), dim3(256), 0, sm, nL, st->valid, st->pos, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl);
+        TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
+        hipLaunchKernelGGL(k_compact<TrackedOp>, dim3(1), dim3(1024), 0, sm, top, nL, st->counts + 6);
         ST_CHECK(hipMemcpyAsync(st->h_counts, st->counts + 6, 4, hipMemcpyDeviceToHost, sm));
     }
     if (nC > 0)   // queued before the host waits for the tracked count
@@ -643,31 +641,32 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
     if (M > 0) {
         vo_strides s2 = {1, cl}, s3 = {1, cl};
         if ((rc = vo_launch_reproj(ctx, st->vk, s2, st->vl, s3, M, pose_now, 0, st->K, st->err))) return rc;
-        hipLaunchKernelGGL(k_flag_less, dim3(blocks(M)), dim3(256), 0, sm, st->err, M, o.max_reproj_err, st->flag);
-        hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, sm, st->flag, M, nullptr, st->pos, st->counts + 7);
-        hipLaunchKernelGGL(k_gather_kept, dim3(blocks(M)), dim3(256), 0, sm, M, st->flag, st->pos, st->vk, st->vl, st->err, cl, pw,
-                           st->wkp, st->wL, st->wrep, st->alive);
+        KeptOp kop = {st->err, o.max_reproj_err, st->vk, st->vl, cl, pw, st->wkp, st->wL, st->wrep, st->alive};
+        hipLaunchKernelGGL(k_compact<KeptOp>, dim3(1), dim3(1024), 0, sm, kop, M, st->counts + 7);
     }
     // [4] :322 -> :63-151 triangulate the tracked candidates, classify, merge in candidate order
     if (nC > 0) {
         vo_strides c2 = {1, cc}, c3 = {1, cc};
         if ((rc = vo_launch_triangulate(ctx, st->cf[s], st->cq, c2, st->poses, 0, st->cpose[s], nC, st->P, pose_now, st->K, st->X, c3,
                                         st->crep, st->cang, st->cok))) return rc;
-        hipLaunchKernelGGL(k_classify, dim3(blocks(nC)), dim3(256), 0, sm, nC, st->cvalid, st->cok, st->crep, st->cang, st->ctime[s],
-                           o.max_reproj_err, o.angular_threshold_deg, o.max_temporal_recall, st->cls, st->keepf);
+        const ClassifyArgs ca = {st->cvalid, st->cok, st->crep, st->cang, st->ctime[s], o.max_reproj_err, o.angular_threshold_deg,
+                                 o.max_temporal_recall};
         MergeArgs m;
         m.nC = nC; m.cap = cl; m.PW = pw; m.capC = cc; m.cls = st->cls; m.X = st->X; m.crep = st->crep; m.cq = st->cq;
         m.wkp = st->wkp; m.wL = st->wL; m.wrep = st->wrep; m.alive = st->alive; m.n0 = st->counts + 7; m.plist = st->plist;
-        m.n_promoted = st->counts + 8;
-        if (pw <= MERGE_LDS) hipLaunchKernelGGL(k_merge_par, dim3(1), dim3(1024), 0, sm, m);   // the usual sizes
-        else hipLaunchKernelGGL(k_merge, dim3(1), dim3(64), 0, sm, m);                          // sequential, any size
-        hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, sm, st->keepf, nC, nullptr, st->pos, st->counts + 1);
-        hipLaunchKernelGGL(k_gather_candidates, dim3(blocks(nC)), dim3(256), 0, sm, nC, st->keepf, st->pos, cc, st->cq, st->cf[s],
-                           st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]);
+        m.n_promoted = st->counts + 8; m.c = ca;
+        if (pw <= MERGE_LDS) {   // the usual sizes
+            hipLaunchKernelGGL(k_merge_par, dim3(1), dim3(1024), 0, sm, m);
+        } else {                 // sequential, any size
+            hipLaunchKernelGGL(k_classify, dim3(blocks(nC)), dim3(256), 0, sm, nC, st->cvalid, st->cok, st->crep, st->cang, st->ctime[s],
+                               o.max_reproj_err, o.angular_threshold_deg, o.max_temporal_recall, st->cls, st->keepf);
+            hipLaunchKernelGGL(k_merge, dim3(1), dim3(64), 0, sm, m);
+        }
+        CandOp cop = {ca, cc, st->cq, st->cf[s], st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]};
+        hipLaunchKernelGGL(k_compact<CandOp>, dim3(1), dim3(1024), 0, sm, cop, nC, st->counts + 1);
     }
-    hipLaunchKernelGGL(k_scan_flags, dim3(1), dim3(1024), 0, sm, st->alive, pw, nullptr, st->pos, st->counts + 0);
-    hipLaunchKernelGGL(k_gather_landmarks, dim3(blocks(pw)), dim3(256), 0, sm, pw, st->alive, st->pos, pw, cl, st->wkp, st->wL, st->wrep,
-                       st->kp[n], st->L[n], st->rep[n]);
+    LandmarkOp lop = {st->alive, pw, cl, st->wkp, st->wL, st->wrep, st->kp[n], st->L[n], st->rep[n]};
+    hipLaunchKernelGGL(k_compact<LandmarkOp>, dim3(1), dim3(1024), 0, sm, lop, pw, st->counts + 0);
     // [5b] :330-345 new candidates away from every tracked point; the number of existing points stays on the
     // device (counts[0] + counts[1]), so the host does not wait here
     hipLaunchKernelGGL(k_existing, dim3(blocks(pw)), dim3(256), 0, sm, st->counts, cl, cc, st->kp[n], st->cu[n], st->eu, st->ev);

@@ -220,11 +220,13 @@ __device__ __forceinline__ void bearing(const double* K, double u, double v, dou
 struct HypArgs {
     const double* xy; vo_strides sxy; const double* X; vo_strides sX; int M;
     const double* K; int H; uint64_t seed; const int32_t* sample_idx; double* Rt;
+    int h0;                 // first hypothesis of this launch (a later stage of the adaptive run)
+    const int32_t* stopped; // non-null: the earlier stage's "adaptive stop reached" flag; nothing to do when set
 };
 
 __global__ __launch_bounds__(64) void k_hyp(HypArgs a) {
-    const int h = blockIdx.x * 64 + threadIdx.x;
-    if (h >= a.H) return;
+    const int h = a.h0 + blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.H || (a.stopped && *a.stopped)) return;
     double K[9];
     for (int k = 0; k < 9; ++k) K[k] = a.K[k];
     int32_t id[3];
@@ -286,13 +288,16 @@ struct ScoreArgs {
     const double* xy; vo_strides sxy; const double* X; vo_strides sX; int M;
     const double* K; int H; double thr2; const double* Rt; int32_t* cnt; unsigned long long* cost;
     unsigned long long* counters;
+    int h0;                 // first hypothesis of this launch
+    const int32_t* stopped; // as in HypArgs
 };
 
 __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
     __shared__ double sRt[SC_NS * 12];
     __shared__ int s_cnt[4][SC_NS];
     __shared__ unsigned long long s_cost[4][SC_NS];
-    const int h0 = blockIdx.x * SC_HB;
+    if (a.stopped && *a.stopped) return;   // uniform: the whole launch has nothing to do
+    const int h0 = a.h0 + blockIdx.x * SC_HB;
     const int tid = threadIdx.x;
     if (tid < SC_NS * 12) {
         const int hs = tid / 12;             // pose within the block
@@ -391,8 +396,9 @@ __device__ __forceinline__ double ransac_limit(double confidence, int bcnt, int 
 
 struct BestArgs {
     const int32_t* cnt; const unsigned long long* cost; const double* Rt; int H, M, mode, min_inl;
-    double confidence; double* out; // R_cw(9) t_cw(3) then 5 int32
+    double confidence; double* out; // R_cw(9) t_cw(3) then 6 int32: status, hyp, sol, trials, inliers, stopped
     int sample_size;                // 3 (P3P) or 8 (eight-point)
+    int later_stage;                // 1: an earlier stage ran on a prefix; keep its record if it reached the stop
 };
 
 __device__ __forceinline__ BState combine(int mode, int min_inl, const BState& earlier, const BState& later) {
@@ -410,11 +416,13 @@ __device__ __forceinline__ BState shfl_up_state(const BState& x, int d) {
 // scan of the best-so-far records (wave shuffles, then the 16 wave totals through LDS), then a
 // re-walk of the chunk with the carried-in record that looks for the adaptive stop.
 constexpr int BEST_NT = 1024;
+constexpr int RANSAC_STAGE = 256;  // hypotheses of the first stage of an adaptive run (a multiple of 64 and of SC_HB)
 __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
     __shared__ BState s_wave[BEST_NT / 64];
     __shared__ int s_stop;
     __shared__ BState s_fin;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (a.later_stage && ((const int32_t*)(a.out + 12))[5]) return;   // uniform
     const int per = (a.H + BEST_NT - 1) / BEST_NT;
     const int lo = min(tid * per, a.H), hi = min(lo + per, a.H);
     BState none; none.h = -1; none.s = -1; none.c = 0; none.q = ~0ull;
@@ -474,6 +482,7 @@ __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
             info[0] = 2;
         }
         info[1] = fin.h; info[2] = fin.s; info[3] = used; info[4] = 0;
+        info[5] = gstop == 0x7fffffff ? 0 : 1;   // the adaptive stop was reached inside these H hypotheses
     }
 }
 
@@ -516,22 +525,30 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
     if (H < 1 || M < 4 || !(o->max_reproj_err > 0)) { ctx->last_error = "ransac: need num_hyp >= 1, M >= 4, max_reproj_err > 0"; return VO_ERR_BAD_ARG; }
     if (o->mode != 0 && o->mode != 1) { ctx->last_error = "ransac: mode must be 0 or 1"; return VO_ERR_BAD_ARG; }
     const double thr2 = o->max_reproj_err * o->max_reproj_err;
-    const double* Rt = w->Rt;
-    if (d_poses_in) Rt = d_poses_in;
-    else {
-        HypArgs h;
-        h.xy = d_xy; h.sxy = sxy; h.X = d_X; h.sX = sX; h.M = M; h.K = d_K; h.H = H; h.seed = o->seed;
-        h.sample_idx = d_sample_idx; h.Rt = w->Rt;
-        hipLaunchKernelGGL(k_hyp, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, h);
+    const double* Rt = d_poses_in ? d_poses_in : w->Rt;
+    // With the adaptive stop (confidence > 0) the sequential semantics usually end after a few trials, and
+    // the record at the stop depends on the hypotheses before it only.  So a first stage generates, scores
+    // and scans the first RANSAC_STAGE hypotheses; the second stage (the rest, then the scan over all H)
+    // returns at once when the first one reached the stop.  Same result as one stage over all H.
+    const int32_t* stopped = (const int32_t*)((const double*)d_out + 12) + 5;
+    const bool staged = o->confidence > 0 && H > 2 * RANSAC_STAGE;
+    for (int stage = 0; stage < (staged ? 2 : 1); ++stage) {
+        const int h0 = stage == 0 ? 0 : RANSAC_STAGE, h1 = (staged && stage == 0) ? RANSAC_STAGE : H;
+        if (!d_poses_in) {
+            HypArgs h;
+            h.xy = d_xy; h.sxy = sxy; h.X = d_X; h.sX = sX; h.M = M; h.K = d_K; h.H = h1; h.seed = o->seed;
+            h.sample_idx = d_sample_idx; h.Rt = w->Rt; h.h0 = h0; h.stopped = stage ? stopped : nullptr;
+            hipLaunchKernelGGL(k_hyp, dim3((h1 - h0 + 63) / 64), dim3(64), 0, ctx->stream, h);
+        }
+        ScoreArgs s;
+        s.xy = d_xy; s.sxy = sxy; s.X = d_X; s.sX = sX; s.M = M; s.K = d_K; s.H = h1; s.thr2 = thr2; s.Rt = Rt;
+        s.cnt = w->cnt; s.cost = w->cost; s.counters = ctx->d_counters; s.h0 = h0; s.stopped = stage ? stopped : nullptr;
+        hipLaunchKernelGGL(k_score, dim3((h1 - h0 + SC_HB - 1) / SC_HB), dim3(256), 0, ctx->stream, s);
+        BestArgs b;
+        b.cnt = w->cnt; b.cost = w->cost; b.Rt = Rt; b.H = h1; b.M = M; b.mode = o->mode; b.min_inl = o->min_inliers;
+        b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 3; b.later_stage = stage;
+        hipLaunchKernelGGL(k_best, dim3(1), dim3(BEST_NT), 0, ctx->stream, b);
     }
-    ScoreArgs s;
-    s.xy = d_xy; s.sxy = sxy; s.X = d_X; s.sX = sX; s.M = M; s.K = d_K; s.H = H; s.thr2 = thr2; s.Rt = Rt;
-    s.cnt = w->cnt; s.cost = w->cost; s.counters = ctx->d_counters;
-    hipLaunchKernelGGL(k_score, dim3((H + SC_HB - 1) / SC_HB), dim3(256), 0, ctx->stream, s);
-    BestArgs b;
-    b.cnt = w->cnt; b.cost = w->cost; b.Rt = Rt; b.H = H; b.M = M; b.mode = o->mode; b.min_inl = o->min_inliers;
-    b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 3;
-    hipLaunchKernelGGL(k_best, dim3(1), dim3(BEST_NT), 0, ctx->stream, b);
     InlArgs in;
     in.xy = d_xy; in.sxy = sxy; in.X = d_X; in.sX = sX; in.M = M; in.K = d_K; in.thr2 = thr2; in.out = (double*)d_out;
     in.inliers = d_inliers;
@@ -787,7 +804,7 @@ int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_
     }
     BestArgs b;
     b.cnt = w->cnt; b.cost = w->cost; b.Rt = w->Rt; b.H = H; b.M = M; b.mode = 1; b.min_inl = o->min_inliers;
-    b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 8;
+    b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 8; b.later_stage = 0;
     hipLaunchKernelGGL(k_best, dim3(1), dim3(BEST_NT), 0, ctx->stream, b);
     EInlArgs in;
     in.p0 = d_p0; in.p1 = d_p1; in.sp = sp; in.M = M; in.K = d_K; in.thr = o->max_reproj_err; in.out = (double*)d_out; in.inliers = d_inliers;
