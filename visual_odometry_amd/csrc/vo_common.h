@@ -105,12 +105,14 @@ int vo_launch_angle(vo_ctx* ctx, const double* d_X, vo_strides sX, int n, const 
 int vo_launch_in_front(vo_ctx* ctx, const double* d_cam, int cam_col_major, const double* d_X, vo_strides sX,
                        int n, uint8_t* d_valid);
 int vo_launch_reproj(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int n,
-                     const double* d_pose, int pose_col_major, const double* d_K, double* d_err);
+                     const double* d_pose, int pose_col_major, const double* d_K, double* d_err,
+                     const int32_t* d_n = nullptr);   // d_n: the count on the device (n is then its upper bound)
 
 struct vo_ransac_work { double* Rt; int32_t* cnt; unsigned long long* cost; };
 int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int M,
                      const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
-                     const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers);
+                     const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers,
+                     const int32_t* d_M = nullptr);   // d_M: the point count on the device (M is then its upper bound)
 int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_strides sp, int M, const double* d_K,
                         const vo_ransac_opts* o, const int32_t* d_sample_idx, const double* d_E_in, vo_ransac_work* w,
                         void* d_out, uint8_t* d_inliers);

@@ -3,8 +3,8 @@
 // The MATLAB state struct lives in HBM as structure-of-arrays; the five steps of a frame run on the
 // ctx stream through the same launchers as the stand-alone entry points (vo_launch_klt, _ransac,
 // _reproj, _triangulate, _select), glued by the small ordered-compaction / merge kernels below.
-// Per frame the host reads back three small records (the tracked count, the new landmark /
-// kept-candidate counts, the final counts + pose); no point data crosses PCIe.
+// Per frame the host reads back one small record at the end (counts + pose + status); every intermediate
+// count stays on the device and sizes its consumers from there; no point data crosses PCIe.
 // Normative restatement: oracle/vo_frame.py.
 #include <string.h>
 #include <algorithm>
@@ -35,8 +35,9 @@ __device__ __forceinline__ int block_excl_scan_1024(int flag, int* total, int* s
 // ordered compaction in one launch: Op::flag(i) says whether element i stays, Op::move(i, d) puts it at
 // position d of the output; *count = number kept.  One block walks the n elements 1024 at a time.
 template <class Op>
-__global__ __launch_bounds__(1024) void k_compact(Op op, int n, int32_t* count) {
+__global__ __launch_bounds__(1024) void k_compact(Op op, int n, int32_t* count, const int32_t* n_dev = nullptr) {
     __shared__ int s_w[16];
+    if (n_dev) n = min(n, *n_dev);   // the count lives on the device, n is its upper bound
     int base = 0;
     for (int i0 = 0; i0 < n; i0 += 1024) {
         const int i = i0 + (int)threadIdx.x;
@@ -608,7 +609,8 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
 
     // [1] :278-281 and :71 track the landmarks' keypoints and the candidates in one launch; keep the
     // validly tracked landmarks in order
-    int M = 0;
+    // The number M of validly tracked landmarks stays on the device (counts[6]): the pose step, the
+    // reprojection filter and the compaction are sized by its upper bound nL and read M themselves.
     if (nL + nC > 0) {
         hipLaunchKernelGGL(k_concat_points, dim3(blocks(nL + nC)), dim3(256), 0, sm, nL, nC, cl, cc, st->kp[s], st->cu[s], st->pin, pw);
         if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->pin, st->pin + pw, nL + nC, o.klt.block_w, o.klt.block_h,
@@ -616,33 +618,28 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
     }
     if (nL > 0) {
         TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
-        hipLaunchKernelGGL(k_compact<TrackedOp>, dim3(1), dim3(1024), 0, sm, top, nL, st->counts + 6);
-        ST_CHECK(hipMemcpyAsync(st->h_counts, st->counts + 6, 4, hipMemcpyDeviceToHost, sm));
+        hipLaunchKernelGGL(k_compact<TrackedOp>, dim3(1), dim3(1024), 0, sm, top, nL, st->counts + 6, nullptr);
     }
-    if (nC > 0)   // queued before the host waits for the tracked count
+    if (nC > 0)
         hipLaunchKernelGGL(k_split_candidates, dim3(blocks(nC)), dim3(256), 0, sm, nL, nC, cc, pw, st->q, st->valid, st->cq, st->cvalid);
-    if (nL > 0) {
-        ST_CHECK(hipStreamSynchronize(sm));
-        M = st->h_counts[0];
-    }
-    // [2] :285-289 pose
-    if (M >= 4) {
+    // [2] :285-289 pose (fewer than 4 tracked points: status 1 and the identity, as the toolbox function errors out)
+    if (nL >= 4) {
         vo_ransac_opts ro = o.pose;
         ro.seed = o.pose.seed + (uint64_t)frame_no;
         vo_ransac_work w;
         if ((rc = vo_int_ransac_work_prepare(ctx, ro.num_hyp, &w))) return rc;
         vo_strides s2 = {1, cl}, s3 = {1, cl};
-        if ((rc = vo_launch_ransac(ctx, st->vk, s2, st->vl, s3, M, st->K, &ro, nullptr, nullptr, &w, st->rsout, st->inl))) return rc;
+        if ((rc = vo_launch_ransac(ctx, st->vk, s2, st->vl, s3, nL, st->K, &ro, nullptr, nullptr, &w, st->rsout, st->inl, st->counts + 6))) return rc;
     } else {
         hipLaunchKernelGGL(k_identity_record, dim3(1), dim3(1), 0, sm, st->rsout, 1);
     }
     hipLaunchKernelGGL(k_pose_from_rt, dim3(1), dim3(1), 0, sm, st->rsout, pose_now);
     // [3] :298-315 reprojection error, strict filter, survivors into the merge arrays
-    if (M > 0) {
+    if (nL > 0) {
         vo_strides s2 = {1, cl}, s3 = {1, cl};
-        if ((rc = vo_launch_reproj(ctx, st->vk, s2, st->vl, s3, M, pose_now, 0, st->K, st->err))) return rc;
+        if ((rc = vo_launch_reproj(ctx, st->vk, s2, st->vl, s3, nL, pose_now, 0, st->K, st->err, st->counts + 6))) return rc;
         KeptOp kop = {st->err, o.max_reproj_err, st->vk, st->vl, cl, pw, st->wkp, st->wL, st->wrep, st->alive};
-        hipLaunchKernelGGL(k_compact<KeptOp>, dim3(1), dim3(1024), 0, sm, kop, M, st->counts + 7);
+        hipLaunchKernelGGL(k_compact<KeptOp>, dim3(1), dim3(1024), 0, sm, kop, nL, st->counts + 7, st->counts + 6);
     }
     // [4] :322 -> :63-151 triangulate the tracked candidates, classify, merge in candidate order
     if (nC > 0) {
@@ -663,10 +660,10 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
             hipLaunchKernelGGL(k_merge, dim3(1), dim3(64), 0, sm, m);
         }
         CandOp cop = {ca, cc, st->cq, st->cf[s], st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]};
-        hipLaunchKernelGGL(k_compact<CandOp>, dim3(1), dim3(1024), 0, sm, cop, nC, st->counts + 1);
+        hipLaunchKernelGGL(k_compact<CandOp>, dim3(1), dim3(1024), 0, sm, cop, nC, st->counts + 1, nullptr);
     }
     LandmarkOp lop = {st->alive, pw, cl, st->wkp, st->wL, st->wrep, st->kp[n], st->L[n], st->rep[n]};
-    hipLaunchKernelGGL(k_compact<LandmarkOp>, dim3(1), dim3(1024), 0, sm, lop, pw, st->counts + 0);
+    hipLaunchKernelGGL(k_compact<LandmarkOp>, dim3(1), dim3(1024), 0, sm, lop, pw, st->counts + 0, nullptr);
     // [5b] :330-345 new candidates away from every tracked point; the number of existing points stays on the
     // device (counts[0] + counts[1]), so the host does not wait here
     hipLaunchKernelGGL(k_existing, dim3(blocks(pw)), dim3(256), 0, sm, st->counts, cl, cc, st->kp[n], st->cu[n], st->eu, st->ev);
@@ -686,7 +683,7 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
     memcpy(ri, st->h_rec + 12, sizeof ri);
     memcpy(pose43, st->h_rec + 16, 96);
     info->status = ri[0]; info->trials_used = ri[3]; info->n_inliers = ri[4];
-    info->n_landmarks = st->h_counts[0]; info->n_candidates = st->h_counts[3]; info->n_tracked = M;
+    info->n_landmarks = st->h_counts[0]; info->n_candidates = st->h_counts[3]; info->n_tracked = st->h_counts[6];
     info->n_promoted = st->h_counts[8]; info->n_new = st->h_counts[5]; info->overflow = st->h_counts[4];
     info->frame_no = frame_no;
     st->nL = std::min(st->h_counts[0], cl); st->nC = st->h_counts[3];

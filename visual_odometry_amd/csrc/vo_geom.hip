@@ -177,9 +177,10 @@ __global__ __launch_bounds__(256) void k_in_front(const double* cam_, int cam_co
 }
 
 __global__ __launch_bounds__(256) void k_reproj(const double* xy, vo_strides sxy, const double* X, vo_strides sX, int n,
-                                                const double* pose_, int pose_col_major, const double* K_, double* err) {
+                                                const double* pose_, int pose_col_major, const double* K_, double* err,
+                                                const int32_t* n_dev) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= (n_dev ? min(n, *n_dev) : n)) return;
     double pose[12], K[9], cam[12], Xi[3];
     load43(pose_, pose_col_major, pose);
     for (int k = 0; k < 9; ++k) K[k] = K_[k];
@@ -225,10 +226,10 @@ int vo_launch_in_front(vo_ctx* ctx, const double* d_cam, int cam_col_major, cons
 }
 
 int vo_launch_reproj(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int n,
-                     const double* d_pose, int pose_col_major, const double* d_K, double* d_err) {
+                     const double* d_pose, int pose_col_major, const double* d_K, double* d_err, const int32_t* d_n) {
     if (n <= 0) return VO_OK;
     hipLaunchKernelGGL(k_reproj, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_xy, sxy, d_X, sX, n, d_pose,
-                       pose_col_major, d_K, d_err);
+                       pose_col_major, d_K, d_err, d_n);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }

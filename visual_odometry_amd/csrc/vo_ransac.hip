@@ -222,11 +222,13 @@ struct HypArgs {
     const double* K; int H; uint64_t seed; const int32_t* sample_idx; double* Rt;
     int h0;                 // first hypothesis of this launch (a later stage of the adaptive run)
     const int32_t* stopped; // non-null: the earlier stage's "adaptive stop reached" flag; nothing to do when set
+    const int32_t* M_dev;   // non-null: the point count lives on the device, M is only its upper bound
 };
 
 __global__ __launch_bounds__(64) void k_hyp(HypArgs a) {
     const int h = a.h0 + blockIdx.x * 64 + threadIdx.x;
     if (h >= a.H || (a.stopped && *a.stopped)) return;
+    if (a.M_dev) { a.M = min(a.M, *a.M_dev); if (a.M < 4) return; }
     double K[9];
     for (int k = 0; k < 9; ++k) K[k] = a.K[k];
     int32_t id[3];
@@ -290,6 +292,7 @@ struct ScoreArgs {
     unsigned long long* counters;
     int h0;                 // first hypothesis of this launch
     const int32_t* stopped; // as in HypArgs
+    const int32_t* M_dev;   // as in HypArgs
 };
 
 __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
@@ -297,6 +300,7 @@ __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
     __shared__ int s_cnt[4][SC_NS];
     __shared__ unsigned long long s_cost[4][SC_NS];
     if (a.stopped && *a.stopped) return;   // uniform: the whole launch has nothing to do
+    if (a.M_dev) { a.M = min(a.M, *a.M_dev); if (a.M < 4) return; }
     const int h0 = a.h0 + blockIdx.x * SC_HB;
     const int tid = threadIdx.x;
     if (tid < SC_NS * 12) {
@@ -399,6 +403,7 @@ struct BestArgs {
     double confidence; double* out; // R_cw(9) t_cw(3) then 6 int32: status, hyp, sol, trials, inliers, stopped
     int sample_size;                // 3 (P3P) or 8 (eight-point)
     int later_stage;                // 1: an earlier stage ran on a prefix; keep its record if it reached the stop
+    const int32_t* M_dev;           // as in HypArgs; fewer than 4 points: status 1 and the identity
 };
 
 __device__ __forceinline__ BState combine(int mode, int min_inl, const BState& earlier, const BState& later) {
@@ -423,6 +428,18 @@ __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
     __shared__ BState s_fin;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (a.later_stage && ((const int32_t*)(a.out + 12))[5]) return;   // uniform
+    if (a.M_dev) {
+        a.M = min(a.M, *a.M_dev);
+        if (a.M < 4) {                                                 // estimateWorldCameraPose needs 4 points
+            if (tid == 0) {
+                for (int k = 0; k < 9; ++k) a.out[k] = (k % 4 == 0) ? 1.0 : 0.0;
+                a.out[9] = a.out[10] = a.out[11] = 0.0;
+                int32_t* info = (int32_t*)(a.out + 12);
+                info[0] = 1; info[1] = -1; info[2] = -1; info[3] = 0; info[4] = 0; info[5] = 1;
+            }
+            return;
+        }
+    }
     const int per = (a.H + BEST_NT - 1) / BEST_NT;
     const int lo = min(tid * per, a.H), hi = min(lo + per, a.H);
     BState none; none.h = -1; none.s = -1; none.c = 0; none.q = ~0ull;
@@ -489,12 +506,14 @@ __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
 struct InlArgs {
     const double* xy; vo_strides sxy; const double* X; vo_strides sX; int M; const double* K; double thr2;
     double* out; uint8_t* inliers;
+    const int32_t* M_dev;   // as in HypArgs (flags beyond the device count are written as 0)
 };
 __global__ __launch_bounds__(256) void k_inliers(InlArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     int32_t* info = (int32_t*)(a.out + 12);
     bool in = false;
-    if (i < a.M && info[0] == 0) {
+    const int Md = a.M_dev ? min(a.M, *a.M_dev) : a.M;
+    if (i < Md && info[0] == 0) {
         double P[12];
         for (int k = 0; k < 12; ++k) P[k] = proj_elem(a.out, a.K, k >> 2, k & 3);
         const ProjT p = proj_terms(P, a.X[i * a.sX.xi],
@@ -520,7 +539,7 @@ __global__ __launch_bounds__(64) void k_p3p_batch(const double* P, const double*
 
 int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int M,
                      const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
-                     const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers) {
+                     const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers, const int32_t* d_M) {
     const int H = o->num_hyp;
     if (H < 1 || M < 4 || !(o->max_reproj_err > 0)) { ctx->last_error = "ransac: need num_hyp >= 1, M >= 4, max_reproj_err > 0"; return VO_ERR_BAD_ARG; }
     if (o->mode != 0 && o->mode != 1) { ctx->last_error = "ransac: mode must be 0 or 1"; return VO_ERR_BAD_ARG; }
@@ -537,21 +556,21 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
         if (!d_poses_in) {
             HypArgs h;
             h.xy = d_xy; h.sxy = sxy; h.X = d_X; h.sX = sX; h.M = M; h.K = d_K; h.H = h1; h.seed = o->seed;
-            h.sample_idx = d_sample_idx; h.Rt = w->Rt; h.h0 = h0; h.stopped = stage ? stopped : nullptr;
+            h.sample_idx = d_sample_idx; h.Rt = w->Rt; h.h0 = h0; h.stopped = stage ? stopped : nullptr; h.M_dev = d_M;
             hipLaunchKernelGGL(k_hyp, dim3((h1 - h0 + 63) / 64), dim3(64), 0, ctx->stream, h);
         }
         ScoreArgs s;
         s.xy = d_xy; s.sxy = sxy; s.X = d_X; s.sX = sX; s.M = M; s.K = d_K; s.H = h1; s.thr2 = thr2; s.Rt = Rt;
-        s.cnt = w->cnt; s.cost = w->cost; s.counters = ctx->d_counters; s.h0 = h0; s.stopped = stage ? stopped : nullptr;
+        s.cnt = w->cnt; s.cost = w->cost; s.counters = ctx->d_counters; s.h0 = h0; s.stopped = stage ? stopped : nullptr; s.M_dev = d_M;
         hipLaunchKernelGGL(k_score, dim3((h1 - h0 + SC_HB - 1) / SC_HB), dim3(256), 0, ctx->stream, s);
         BestArgs b;
         b.cnt = w->cnt; b.cost = w->cost; b.Rt = Rt; b.H = h1; b.M = M; b.mode = o->mode; b.min_inl = o->min_inliers;
-        b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 3; b.later_stage = stage;
+        b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 3; b.later_stage = stage; b.M_dev = d_M;
         hipLaunchKernelGGL(k_best, dim3(1), dim3(BEST_NT), 0, ctx->stream, b);
     }
     InlArgs in;
     in.xy = d_xy; in.sxy = sxy; in.X = d_X; in.sX = sX; in.M = M; in.K = d_K; in.thr2 = thr2; in.out = (double*)d_out;
-    in.inliers = d_inliers;
+    in.inliers = d_inliers; in.M_dev = d_M;
     hipLaunchKernelGGL(k_inliers, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, in);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
@@ -804,7 +823,7 @@ int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_
     }
     BestArgs b;
     b.cnt = w->cnt; b.cost = w->cost; b.Rt = w->Rt; b.H = H; b.M = M; b.mode = 1; b.min_inl = o->min_inliers;
-    b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 8; b.later_stage = 0;
+    b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 8; b.later_stage = 0; b.M_dev = nullptr;
     hipLaunchKernelGGL(k_best, dim3(1), dim3(BEST_NT), 0, ctx->stream, b);
     EInlArgs in;
     in.p0 = d_p0; in.p1 = d_p1; in.sp = sp; in.M = M; in.K = d_K; in.thr = o->max_reproj_err; in.out = (double*)d_out; in.inliers = d_inliers;
