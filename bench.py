@@ -76,15 +76,16 @@ def frame_loop_leg(ctx, with_cpu, n_frames=24):
     restatement on the host cores for the first frames of the same sequence."""
     import numpy as np
     import torch
-    from oracle import oracle, vo_frame
-    from visual_odometry_amd import synth
+    from visual_odometry_amd import modules, ops, synth
     from visual_odometry_amd.frame import FrameLoop
     K = synth.KITTI_K
     frames, poses, lift = synth.plane_sequence(n_frames, K, nv=376, nu=1241, depth=20.0, step=(0.2, 0.0, 0.15))
-    u, v, _, _ = oracle.select_candidates(frames[0], np.zeros(0, np.float32), np.zeros(0, np.float32), min_distance=7, keep=300)
-    st = vo_frame.new_state()
-    st.keypoints = np.stack([u, v], 1).astype(np.float64); st.landmarks = lift(st.keypoints[:, 0], st.keypoints[:, 1])
-    st.reproError = np.zeros(len(u))
+    kp = ops.select_candidates(frames[0], np.zeros((0, 2), np.float32), min_distance=7, min_quality=0.001, keep=300,
+                               index_base=0, ctx=ctx).astype(np.float64)
+    st = modules._new_state()
+    st.keypoints = kp; st.landmarks = lift(kp[:, 0], kp[:, 1])
+    st.reproError = np.zeros(len(kp))
+    st.candidate_first_poses = np.zeros((0, 4, 3))
     dev = [torch.from_numpy(f).to(f"cuda:{ctx.device}") for f in frames]
     loop = FrameLoop(K, frames[0].shape, ctx=ctx)
     best = None
@@ -101,7 +102,31 @@ def frame_loop_leg(ctx, with_cpu, n_frames=24):
            "workload": "vo_frame_process: 1241x376, maxNumLandmarks 300, 100 new candidates/frame, 4-level 41x41 KLT, "
                        "<= 5000 P3P trials (99 %), min-eigen selection; frames resident in HBM, state never leaves HBM"}
     loop.close()
-    if with_cpu:
+    # the same loop at BASELINE configs[1]'s size: ~2k tracked keypoints per KITTI-shaped frame
+    kp2 = ops.select_candidates(frames[0], np.zeros((0, 2), np.float32), min_distance=7, min_quality=0.001, keep=2000,
+                                index_base=0, ctx=ctx).astype(np.float64)
+    st2 = modules._new_state()
+    st2.keypoints = kp2; st2.landmarks = lift(kp2[:, 0], kp2[:, 1]); st2.reproError = np.zeros(len(kp2))
+    st2.candidate_first_poses = np.zeros((0, 4, 3))
+    loop2 = FrameLoop(K, frames[0].shape, maxNumLandmarks=2000, CandidatesToKeep=300, ctx=ctx)
+    best2 = None
+    for _ in range(3):
+        loop2.set_state(st2, dev[0])
+        ctx.sync()
+        t0 = time.perf_counter()
+        for k in range(1, n_frames):
+            pose2, status2, info2 = loop2.processFrame(dev[k])
+        dt = time.perf_counter() - t0
+        best2 = dt if best2 is None else min(best2, dt)
+    loop2.close()
+    out["at_2k_landmarks"] = {"ms_per_frame": 1e3 * best2 / (n_frames - 1), "frames_per_s": (n_frames - 1) / best2,
+                              "start_landmarks": len(kp2), "final_landmarks": info2["n_landmarks"],
+                              "final_candidates": info2["n_candidates"], "tracked_last_frame": info2["n_tracked"],
+                              "pose_status": status2,
+                              "workload": "as above with maxNumLandmarks 2000 and 300 new candidates per frame "
+                                          "(BASELINE configs[1]: ~2k KLT keypoints on a KITTI-shaped frame)"}
+    if with_cpu:                                          # cpu_baseline of this leg: the oracle's restatement
+        from oracle import vo_frame
         threads = min(16, os.cpu_count() or 1)
         m = min(6, n_frames - 1)
         t0 = time.perf_counter()
@@ -109,7 +134,55 @@ def frame_loop_leg(ctx, with_cpu, n_frames=24):
             st, *_ = vo_frame.process_frame(frames[k - 1], frames[k], st, K, k, threads=threads)
         out["cpu_ms_per_frame"] = 1e3 * (time.perf_counter() - t0) / m
         out["cpu_cores"] = threads
+    out["ingest"] = ingest_leg(ctx, frames, loop_state=st if not with_cpu else None)
     return out
+
+
+def ingest_leg(ctx, frames, loop_state=None, n_files=96, threads=8):
+    """Extra leg: the decode pool on KITTI-shaped gray PNG files (written here with zlib, rows
+    filtered with 'Up'), alone: files -> device images per second on `threads` host threads."""
+    import shutil
+    import struct
+    import tempfile
+    import zlib
+    import numpy as np
+    from visual_odometry_amd import ingest
+
+    def png(img):
+        h, w = img.shape
+        d = img.astype(np.int16)
+        d[1:] -= img[:-1].astype(np.int16)               # filter type 2 (Up)
+        raw = np.concatenate([np.full((h, 1), 2, np.uint8), (d & 255).astype(np.uint8)], 1).tobytes()
+
+        def chunk(t, b):
+            return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b))
+        return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+    tmp = tempfile.mkdtemp(prefix="vo_bench_ingest_")
+    try:
+        blobs = [png(f) for f in frames[:8]]
+        paths = []
+        for i in range(n_files):
+            p = os.path.join(tmp, "%06d.png" % i)
+            with open(p, "wb") as f:
+                f.write(blobs[i % len(blobs)])
+            paths.append(p)
+        best = None
+        for _ in range(2):
+            fs = ingest.FrameStream(paths, threads=threads, ctx=ctx)
+            ctx.sync()
+            t0 = time.perf_counter()
+            n = sum(1 for _ in fs)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            st = fs.stats()
+            fs.close()
+            best = dt if best is None else min(best, dt)
+        return {"files": n, "frames_per_s": n / best, "threads": st.threads, "host_ms_per_file": 1e3 * st.decode_seconds / n,
+                "workload": "vo_ingest_*: %d gray PNG files of 1241x376 (%d kB each, 'Up' rows) -> device images, decode pool "
+                            "alone" % (n, len(blobs[0]) // 1000)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
