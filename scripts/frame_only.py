@@ -1,21 +1,24 @@
-"""GPU-only driver for profiling the device-resident frame loop (vo_frame_process)."""
+"""GPU-only driver for profiling the device-resident frame loop (vo_frame_process).
+    python scripts/frame_only.py [n_frames] [max_landmarks] [new_candidates_per_frame]"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
 import torch
-from oracle import oracle, vo_frame
-from visual_odometry_amd import _lib, synth
+from visual_odometry_amd import _lib, modules, ops, synth
 from visual_odometry_amd.frame import FrameLoop
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+n_land = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+n_new = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 K = synth.KITTI_K
 frames, poses, lift = synth.plane_sequence(n_frames, K, nv=376, nu=1241, depth=20.0, step=(0.2, 0.0, 0.15))
-u, v, _, _ = oracle.select_candidates(frames[0], np.zeros(0, np.float32), np.zeros(0, np.float32), min_distance=7, keep=300)
-st = vo_frame.new_state()
-st.keypoints = np.stack([u, v], 1).astype(np.float64); st.landmarks = lift(st.keypoints[:, 0], st.keypoints[:, 1])
-st.reproError = np.zeros(len(u))
 ctx = _lib.Context(0)
+kp = ops.select_candidates(frames[0], np.zeros((0, 2), np.float32), min_distance=7, min_quality=0.001, keep=n_land, index_base=0,
+                           ctx=ctx).astype(np.float64)
+st = modules._new_state()
+st.keypoints = kp; st.landmarks = lift(kp[:, 0], kp[:, 1]); st.reproError = np.zeros(len(kp))
+st.candidate_first_poses = np.zeros((0, 4, 3))
 dev = [torch.from_numpy(f).to("cuda:0") for f in frames]
-loop = FrameLoop(K, frames[0].shape, ctx=ctx)
+loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=n_land, CandidatesToKeep=n_new, ctx=ctx)
 for rep in range(3):
     loop.set_state(st, dev[0]); ctx.sync()
     t0 = time.perf_counter()

@@ -148,9 +148,9 @@ def test_device_images_and_kitti_shape(ctx):
 
 
 def test_merge_beyond_the_lds_copies(ctx, sequence):
-    """2600 promotable candidates against a landmark cap of 5000 + 3000 candidates: the merge kernel's
-    LDS copies (4096 entries, 2048 promotable) do not fit, so its global-array paths run; then the same
-    candidates against a cap of 150, where almost every one replaces the worst landmark."""
+    """2600 promotable candidates against a landmark cap of 5000 + 3000 candidates (a pool beyond the one-block
+    merge's 4096 LDS entries), then against a cap of 150, where almost every one replaces the worst landmark:
+    both through the three-launch merge (list, all-pairs counts over the chip, ordered write)."""
     frames, poses, lift = sequence
     k = 8
     rng = np.random.default_rng(5)

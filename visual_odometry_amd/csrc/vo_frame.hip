@@ -136,138 +136,23 @@ __global__ void k_identity_record(double* out, int status) {
     info[0] = status; info[1] = -1; info[2] = -1; info[3] = 0; info[4] = 0;
 }
 
-// :106-113, :130: 0 drop, 1 promote (angle large), 2 keep as candidate (angle small, young enough)
-__global__ void k_classify(int n, const uint8_t* tracked, const uint8_t* ok, const double* rep, const double* ang,
-                           const int32_t* ctime, double max_rep, double ang_thr, int recall, uint8_t* cls, uint8_t* keepf) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int c = 0;
-    if (tracked[i] && ok[i] && rep[i] <= max_rep) {
-        if (ang[i] > ang_thr) c = 1;
-        else if (ctime[i] > -recall) c = 2;
-    }
-    cls[i] = (uint8_t)c;
-    keepf[i] = c == 2;
-}
-
-// The order-dependent merge of :87-142 over the promotable candidates, in candidate order.
-// Landmarks are never moved: a replaced landmark (:116-122) is tombstoned, an
-// accepted one appended (:123-127); the ordered compaction afterwards gives the MATLAB order.
+// The order-dependent merge of :87-142 over the promotable candidates, in candidate order: at the landmark
+// cap a candidate replaces the FIRST maximum of reproError if its own error is not larger (:116-122, maximum
+// taken before the edit), below the cap it is appended (:123-127).  Landmarks are never moved: an evicted
+// one is tombstoned, an accepted one appended; the ordered compaction afterwards gives the MATLAB order.
 struct MergeArgs {
     int nC, cap, PW, capC;
-    const uint8_t* cls;
     const double *X, *crep, *cq;    // candidates: pitch capC
     double *wkp, *wL, *wrep; uint8_t* alive;
     const int32_t* n0;              // landmarks that survived the reprojection filter
     int32_t* plist;                 // scratch, nC
     int32_t* n_promoted;
-    ClassifyArgs c;                 // k_merge_par classifies inline; k_merge reads cls
+    ClassifyArgs c;                 // which candidates are promotable (class 1)
 };
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ unsigned dpp_u32(unsigned x) {
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWMASK, 0xf, false); // lanes without a source read 0
-}
-// maximum over the 64 lanes, result uniform (DPP row operations, as wave_sum in vo_klt.hip)
-__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
-    x = max(x, dpp_u32<0xb1, 0xf>(x));  // quad_perm [1,0,3,2]
-    x = max(x, dpp_u32<0x4e, 0xf>(x));  // quad_perm [2,3,0,1]
-    x = max(x, dpp_u32<0x114, 0xf>(x)); // row_shr:4
-    x = max(x, dpp_u32<0x118, 0xf>(x)); // row_shr:8
-    x = max(x, dpp_u32<0x142, 0xa>(x)); // row_bcast:15
-    x = max(x, dpp_u32<0x143, 0xc>(x)); // row_bcast:31
-    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
-}
+constexpr int MERGE_LDS = 4096;       // pool entries (landmarks + promotable candidates) of the one-block form
+constexpr int MERGE_ONE_BLOCK = 768;  // landmarks + candidates up to which the single block is the fastest form
 
-// One wave: every step is wave-synchronous.  For the usual sizes the reprojection errors, the
-// tombstones and the promotable candidates' errors sit in LDS and the loop touches nothing else:
-// global memory is read before it and the accepted landmarks are written after it, in parallel.
-constexpr int MERGE_LDS = 4096; // landmarks + appended entries that fit the LDS copy (else global arrays)
-constexpr int MERGE_PL = 2048;  // promotable candidates that fit the LDS list (else global arrays)
-__global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
-    __shared__ double s_rep[MERGE_LDS];
-    __shared__ uint8_t s_alv[MERGE_LDS];
-    __shared__ double s_prep[MERGE_PL];
-    __shared__ int32_t s_pidx[MERGE_PL];
-    const int lane = threadIdx.x;
-    const int n0 = *a.n0;
-    // ordered list of the promotable candidates
-    int np = 0;
-    for (int i0 = 0; i0 < a.nC; i0 += 64) {
-        const int i = i0 + lane;
-        const int f = (i < a.nC && a.cls[i] == 1) ? 1 : 0;
-        const unsigned long long bal = __ballot(f);
-        if (f) a.plist[np + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-        np += __popcll(bal);
-    }
-    __syncthreads();
-    const bool in_lds = a.PW <= MERGE_LDS, pl_lds = np <= MERGE_PL;
-    double* rep = in_lds ? s_rep : a.wrep;
-    uint8_t* alv = in_lds ? s_alv : a.alive;
-    if (in_lds)
-        for (int k = lane; k < n0; k += 64) { s_rep[k] = a.wrep[k]; s_alv[k] = a.alive[k]; }
-    if (pl_lds)
-        for (int j = lane; j < np; j += 64) { const int i = a.plist[j]; s_pidx[j] = i; s_prep[j] = a.crep[i]; }
-    __syncthreads();
-    int alive_n = n0, tot = n0, prom = 0;   // wave-uniform
-    // every lane caches the first maximum (bv at bi) of its share {k = lane mod 64} of the live
-    // landmarks; an edit re-scans only the share it touches
-    double bv = 0; int bi = -1;
-    bool cached = false;
-    for (int j = 0; j < np; ++j) {
-        const double r = pl_lds ? s_prep[j] : a.crep[a.plist[j]];
-        if (alive_n >= a.cap) {
-            if (!cached) {
-                bv = 0; bi = -1;
-                for (int k = lane; k < tot; k += 64)
-                    if (alv[k]) { const double v = rep[k]; if (bi < 0 || v > bv) { bv = v; bi = k; } }
-                cached = true;
-            }
-            // :89-90 first maximum of reproError: errors are >= 0, so their bit patterns order like
-            // the values; maximum of the high words, then of the low words among those, then the
-            // lowest index among equals
-            const unsigned long long key = bi >= 0 ? (unsigned long long)__double_as_longlong(bv) + 1ull : 0ull;
-            const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
-            const unsigned mhi = wave_max_u32(hi);
-            const unsigned mlo = wave_max_u32(hi == mhi ? lo : 0u);
-            const bool win = bi >= 0 && hi == mhi && lo == mlo;
-            const unsigned mix = wave_max_u32(win ? 0xffffffffu - (unsigned)bi : 0u);
-            if (mix != 0u) {
-                const int mi = (int)(0xffffffffu - mix);
-                const double mv = __longlong_as_double((long long)((((unsigned long long)mhi << 32) | mlo) - 1ull));
-                if (r <= mv) {                                                         // :116-122
-                    if (lane == (mi & 63)) {
-                        alv[mi] = 0;
-                        bv = 0; bi = -1;
-                        for (int k = lane; k < tot; k += 64)
-                            if (alv[k]) { const double v = rep[k]; if (bi < 0 || v > bv) { bv = v; bi = k; } }
-                    }
-                    alive_n -= 1;
-                }
-            }
-        }
-        if (alive_n < a.cap) {                                                         // :123-127
-            if (lane == (tot & 63)) {
-                rep[tot] = r; alv[tot] = 1;
-                if (cached && (bi < 0 || r > bv)) { bv = r; bi = tot; }
-            }
-            if (lane == 0) a.plist[prom] = pl_lds ? s_pidx[j] : a.plist[j];   // accepted candidates, in order (prom <= j)
-            tot += 1; alive_n += 1; prom += 1;
-        }
-        __syncthreads();
-    }
-    // the accepted candidates become landmarks n0 .. n0 + prom - 1 of the work arrays
-    for (int k = lane; k < prom; k += 64) {
-        const int i = a.plist[k], d = n0 + k;
-        a.wL[d] = a.X[i]; a.wL[a.PW + d] = a.X[a.capC + i]; a.wL[2 * a.PW + d] = a.X[2 * a.capC + i];
-        a.wkp[d] = a.cq[i]; a.wkp[a.PW + d] = a.cq[a.capC + i];
-        a.wrep[d] = a.crep[i];
-    }
-    if (in_lds)
-        for (int k = lane; k < tot; k += 64) a.alive[k] = s_alv[k];
-    if (lane == 0) *a.n_promoted = prom;
-}
-
-// The same policy without the sequential loop.  At the cap every accepted candidate evicts the current
+// No sequential loop: at the cap every accepted candidate evicts the current
 // first maximum, so the landmark set is a streaming "cap smallest so far": the maximum never grows, an
 // element below the final maximum T is never evicted, one above T never survives, and among elements equal
 // to T the ones latest in order survive (eviction takes the first maximum; accepted candidates are appended
@@ -275,8 +160,9 @@ __global__ __launch_bounds__(64) void k_merge(MergeArgs a) {
 //   accepted(j)  <=>  #{x before j in order : v_x < r_j} < cap            (what :116-127 decides at j's turn)
 //   survives(e)  <=>  #{x : v_x < v_e} + #{x : v_x = v_e, x after e} < cap
 // Both are all-pairs counts over the pool (landmarks + promotable candidates): one block, every thread
-// owns elements and walks the pool in LDS (broadcast reads).  Identical to k_merge (tests/test_gpu_frame.py
-// runs both; the equivalence is also checked on tie-heavy random pools in tests/test_host_logic.py).
+// owns elements and walks the pool in LDS (broadcast reads).  The equivalence with the sequential policy is
+// checked on tie-heavy random pools (tests/test_host_logic.py) and per frame against the oracle's sequential
+// restatement (tests/test_gpu_frame.py).
 __global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a) {
     __shared__ double s_v[MERGE_LDS];
     __shared__ int32_t s_pidx[MERGE_LDS];
@@ -331,6 +217,72 @@ __global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a) {
     if (tid == 0) *a.n_promoted = prom;
 }
 
+// The same in three launches for pools beyond a few hundred entries, where one block walking all pairs is too
+// slow: the list and the pool (one block), the two counts with 16 lanes per element over the whole chip, the
+// ordered write (one block).  pool: PW doubles; surv / acc: PW bytes each; np_out: one int.
+struct MergeWideArgs { MergeArgs m; double* pool; uint8_t *surv, *acc; int32_t* np_out; };
+
+__global__ __launch_bounds__(1024) void k_merge_list(MergeWideArgs w) {
+    __shared__ int s_w[16];
+    const MergeArgs& a = w.m;
+    const int tid = threadIdx.x;
+    const int n0 = *a.n0;
+    int np = 0;
+    for (int i0 = 0; i0 < a.nC; i0 += 1024) {
+        const int i = i0 + tid;
+        const int f = (i < a.nC && a.c.cls(i) == 1) ? 1 : 0;
+        int tot;
+        const int pos = block_excl_scan_1024(f, &tot, s_w);
+        if (f) { a.plist[np + pos] = i; w.pool[n0 + np + pos] = a.crep[i]; }
+        np += tot;
+    }
+    for (int e = tid; e < n0; e += 1024) w.pool[e] = a.wrep[e];
+    if (tid == 0) *w.np_out = np;
+}
+
+__global__ __launch_bounds__(256) void k_merge_rank(MergeWideArgs w) {
+    const int P = *w.m.n0 + *w.np_out;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int e = g >> 4, slice = g & 15;
+    int rank = 0, before = 0;
+    if (e < P) {
+        const double ve = w.pool[e];
+        for (int x = slice; x < P; x += 16) {
+            const double vx = w.pool[x];
+            const int less = vx < ve;
+            rank += less | ((vx == ve) & (x > e));
+            before += less & (x < e);
+        }
+    }
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) { rank += __shfl_xor(rank, d, 64); before += __shfl_xor(before, d, 64); }
+    if (e < P && slice == 0) { w.surv[e] = rank < w.m.cap; w.acc[e] = before < w.m.cap; }
+}
+
+__global__ __launch_bounds__(1024) void k_merge_write(MergeWideArgs w) {
+    __shared__ int s_w[16];
+    const MergeArgs& a = w.m;
+    const int tid = threadIdx.x;
+    const int n0 = *a.n0, np = *w.np_out;
+    int prom = 0;
+    for (int j0 = 0; j0 < np; j0 += 1024) {
+        const int j = j0 + tid;
+        const int f = (j < np && w.acc[n0 + j]) ? 1 : 0;
+        int tot;
+        const int pos = block_excl_scan_1024(f, &tot, s_w);
+        if (f) {
+            const int i = a.plist[j], d = n0 + prom + pos;
+            a.wL[d] = a.X[i]; a.wL[a.PW + d] = a.X[a.capC + i]; a.wL[2 * a.PW + d] = a.X[2 * a.capC + i];
+            a.wkp[d] = a.cq[i]; a.wkp[a.PW + d] = a.cq[a.capC + i];
+            a.wrep[d] = w.pool[n0 + j];
+            a.alive[d] = w.surv[n0 + j];
+        }
+        prom += tot;
+    }
+    for (int i = tid; i < n0; i += 1024) a.alive[i] = w.surv[i];
+    if (tid == 0) *a.n_promoted = prom;
+}
+
 // :330-331 [keypoints; candidate_keypoints] cast to single
 __global__ void k_existing(const int32_t* counts, int capL, int capC, const double* kp, const double* cu, float* eu, float* ev) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -380,7 +332,7 @@ struct vo_frame_state {
     // work
     double *pin, *q, *vk, *vl, *err, *cq, *X, *crep, *cang, *wkp, *wL, *wrep;
     float *score, *eu, *ev, *su, *sv;
-    uint8_t *valid, *flag, *cvalid, *cok, *cls, *keepf, *alive, *inl;
+    uint8_t *valid, *flag, *cvalid, *cok, *alive, *inl;
     int32_t *pos, *plist, *counts, *slin;
     int32_t* h_counts;                      // pinned
     double* h_rec;                          // pinned: ransac record (16) + pose (12)
@@ -414,7 +366,7 @@ void carve(vo_frame_state* st, char* base, size_t* total) {
     const size_t keep = (size_t)std::max(st->o.sel.keep, 1);
     st->su = b.take<float>(keep); st->sv = b.take<float>(keep); st->slin = b.take<int32_t>(keep);
     st->valid = b.take<uint8_t>(pw); st->flag = b.take<uint8_t>(cl); st->cvalid = b.take<uint8_t>(cc); st->cok = b.take<uint8_t>(cc);
-    st->cls = b.take<uint8_t>(cc); st->keepf = b.take<uint8_t>(cc); st->alive = b.take<uint8_t>(pw); st->inl = b.take<uint8_t>(cl);
+    st->alive = b.take<uint8_t>(pw); st->inl = b.take<uint8_t>(cl);
     st->pos = b.take<int32_t>(pw); st->plist = b.take<int32_t>(cc); st->counts = b.take<int32_t>(16);
     *total = b.off + 256;
 }
@@ -649,15 +601,16 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
         const ClassifyArgs ca = {st->cvalid, st->cok, st->crep, st->cang, st->ctime[s], o.max_reproj_err, o.angular_threshold_deg,
                                  o.max_temporal_recall};
         MergeArgs m;
-        m.nC = nC; m.cap = cl; m.PW = pw; m.capC = cc; m.cls = st->cls; m.X = st->X; m.crep = st->crep; m.cq = st->cq;
+        m.nC = nC; m.cap = cl; m.PW = pw; m.capC = cc; m.X = st->X; m.crep = st->crep; m.cq = st->cq;
         m.wkp = st->wkp; m.wL = st->wL; m.wrep = st->wrep; m.alive = st->alive; m.n0 = st->counts + 7; m.plist = st->plist;
         m.n_promoted = st->counts + 8; m.c = ca;
-        if (pw <= MERGE_LDS) {   // the usual sizes
+        if (pw <= MERGE_LDS && nL + nC <= MERGE_ONE_BLOCK) {   // small pools: one block does it all
             hipLaunchKernelGGL(k_merge_par, dim3(1), dim3(1024), 0, sm, m);
-        } else {                 // sequential, any size
-            hipLaunchKernelGGL(k_classify, dim3(blocks(nC)), dim3(256), 0, sm, nC, st->cvalid, st->cok, st->crep, st->cang, st->ctime[s],
-                               o.max_reproj_err, o.angular_threshold_deg, o.max_temporal_recall, st->cls, st->keepf);
-            hipLaunchKernelGGL(k_merge, dim3(1), dim3(64), 0, sm, m);
+        } else {                                               // the all-pairs counts spread over the chip
+            MergeWideArgs mw = {m, st->pin, (uint8_t*)st->pos, (uint8_t*)st->pos + pw, st->counts + 9};
+            hipLaunchKernelGGL(k_merge_list, dim3(1), dim3(1024), 0, sm, mw);
+            hipLaunchKernelGGL(k_merge_rank, dim3(blocks(16 * (nL + nC))), dim3(256), 0, sm, mw);
+            hipLaunchKernelGGL(k_merge_write, dim3(1), dim3(1024), 0, sm, mw);
         }
         CandOp cop = {ca, cc, st->cq, st->cf[s], st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]};
         hipLaunchKernelGGL(k_compact<CandOp>, dim3(1), dim3(1024), 0, sm, cop, nC, st->counts + 1, nullptr);
