@@ -7,6 +7,7 @@ batched candidate triangulation + angle + cheirality (:87-113) and candidate sel
 torch is used for device memory only.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -120,13 +121,18 @@ class FrameWorkload:
         k = self.k
         a, b = k % 2, (k + 1) % 2
         nxt = (k % self.n_frames) + 1
-        self.select_begin(nxt)     # corner detection on the new image runs beside the pyramid build and tracking
+        two_phase = not os.environ.get("VO_SINGLE_CALL_SELECT")   # A/B switch for profiling
+        if two_phase:
+            self.select_begin(nxt)     # corner detection on the new image runs beside the pyramid build and tracking
         self.build(b, nxt)
         self.track_all(a, b)       # landmarks + candidates in one launch
         if self.nl >= 4:
             self.pose()
         self.triangulate()
-        self.select_finish()       # distance filter against the existing points + selectUniform
+        if two_phase:
+            self.select_finish()       # distance filter against the existing points + selectUniform
+        else:
+            self.select(nxt)
         self.k += 1
         if self.k % self.n_frames == 0:       # loop the sequence: rebuild frame 0 as "previous"
             self.build(self.k % 2, 0)
