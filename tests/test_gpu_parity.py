@@ -379,3 +379,18 @@ def test_ransac_adaptive_run_in_two_stages(ctx, outlier_frac, mode):
     assert (a["best_hyp"], a["best_sol"]) == (b["best_hyp"], b["best_sol"])
     np.testing.assert_array_equal(a["inliers"], b["inliers"])
     np.testing.assert_allclose(a["R"], b["R"], rtol=1e-9, atol=1e-12)
+
+
+def test_ransac_adaptive_run_still_scores_everything_when_asked(ctx):
+    """Per-hypothesis outputs (counts, costs, poses) of an adaptive run cover all hypotheses, not just the first stage."""
+    xy, X, *_ = synth.pnp_scene(1200, seed=78, outlier_frac=0.2)
+    a = ops.p3p_ransac(xy, X, K, num_hyp=1500, max_reproj_err=2.0, confidence=0.99, seed=12, mode=1, min_inliers=4, want_all=True)
+    b = oracle.p3p_ransac(xy, X, K, num_hyp=1500, max_reproj=2.0, confidence=0.99, seed=12, mode=1, min_inliers=4, want_all=True,
+                          threads=8)
+    assert a["trials"] == b["trials"] < 256 and a["counts"].shape == b["counts"].shape == (1500, 4)
+    assert (a["counts"] == b["counts"]).mean() > 0.98 and (a["counts"][300:] > 0).any()   # own hypotheses: equal up to libm ulps
+    s = ops.p3p_ransac(xy, X, K, num_hyp=1500, max_reproj_err=2.0, confidence=0.99, seed=12, mode=1, min_inliers=4,
+                       hyp_poses=b["poses"], want_all=True)
+    np.testing.assert_array_equal(s["counts"], b["counts"])
+    np.testing.assert_array_equal(s["costs"], b["costs"])
+    assert s["trials"] == b["trials"] and s["best_hyp"] == b["best_hyp"]

@@ -112,7 +112,8 @@ struct vo_ransac_work { double* Rt; int32_t* cnt; unsigned long long* cost; };
 int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int M,
                      const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
                      const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers,
-                     const int32_t* d_M = nullptr);   // d_M: the point count on the device (M is then its upper bound)
+                     const int32_t* d_M = nullptr,    // d_M: the point count on the device (M is then its upper bound)
+                     int score_all = 0);              // 1: no early exit of the adaptive run (per-hypothesis outputs wanted)
 int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_strides sp, int M, const double* d_K,
                         const vo_ransac_opts* o, const int32_t* d_sample_idx, const double* d_E_in, vo_ransac_work* w,
                         void* d_out, uint8_t* d_inliers);

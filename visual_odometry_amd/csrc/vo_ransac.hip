@@ -539,7 +539,7 @@ __global__ __launch_bounds__(64) void k_p3p_batch(const double* P, const double*
 
 int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int M,
                      const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
-                     const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers, const int32_t* d_M) {
+                     const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers, const int32_t* d_M, int score_all) {
     const int H = o->num_hyp;
     if (H < 1 || M < 4 || !(o->max_reproj_err > 0)) { ctx->last_error = "ransac: need num_hyp >= 1, M >= 4, max_reproj_err > 0"; return VO_ERR_BAD_ARG; }
     if (o->mode != 0 && o->mode != 1) { ctx->last_error = "ransac: mode must be 0 or 1"; return VO_ERR_BAD_ARG; }
@@ -550,7 +550,7 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
     // and scans the first RANSAC_STAGE hypotheses; the second stage (the rest, then the scan over all H)
     // returns at once when the first one reached the stop.  Same result as one stage over all H.
     const int32_t* stopped = (const int32_t*)((const double*)d_out + 12) + 5;
-    const bool staged = o->confidence > 0 && H > 2 * RANSAC_STAGE;
+    const bool staged = o->confidence > 0 && H > 2 * RANSAC_STAGE && !score_all;   // score_all: the caller reads every hypothesis' counts
     for (int stage = 0; stage < (staged ? 2 : 1); ++stage) {
         const int h0 = stage == 0 ? 0 : RANSAC_STAGE, h1 = (staged && stage == 0) ? RANSAC_STAGE : H;
         if (!d_poses_in) {
