@@ -241,22 +241,32 @@ __global__ __launch_bounds__(1024) void k_merge_list(MergeWideArgs w) {
 }
 
 __global__ __launch_bounds__(256) void k_merge_rank(MergeWideArgs w) {
+    constexpr int TILE = 2048;                 // pool entries staged in LDS at a time
+    __shared__ double s_tile[TILE];
     const int P = *w.m.n0 + *w.np_out;
     const int g = blockIdx.x * 256 + threadIdx.x;
     const int e = g >> 4, slice = g & 15;
+    if ((int)(blockIdx.x * 16) >= P) return;   // uniform: none of the block's 16 elements exists
+    const bool live = e < P;
+    const double ve = live ? w.pool[e] : 0.0;
     int rank = 0, before = 0;
-    if (e < P) {
-        const double ve = w.pool[e];
-        for (int x = slice; x < P; x += 16) {
-            const double vx = w.pool[x];
-            const int less = vx < ve;
-            rank += less | ((vx == ve) & (x > e));
-            before += less & (x < e);
-        }
+    for (int x0 = 0; x0 < P; x0 += TILE) {
+        const int nt = min(TILE, P - x0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nt; k += 256) s_tile[k] = w.pool[x0 + k];
+        __syncthreads();
+        if (live)
+            for (int k = slice; k < nt; k += 16) {
+                const double vx = s_tile[k];
+                const int x = x0 + k;
+                const int less = vx < ve;
+                rank += less | ((vx == ve) & (x > e));
+                before += less & (x < e);
+            }
     }
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) { rank += __shfl_xor(rank, d, 64); before += __shfl_xor(before, d, 64); }
-    if (e < P && slice == 0) { w.surv[e] = rank < w.m.cap; w.acc[e] = before < w.m.cap; }
+    if (live && slice == 0) { w.surv[e] = rank < w.m.cap; w.acc[e] = before < w.m.cap; }
 }
 
 __global__ __launch_bounds__(1024) void k_merge_write(MergeWideArgs w) {
