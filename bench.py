@@ -302,10 +302,10 @@ def main():
                            "parallelism": f"{world} independent sequence(s), one per GPU"},
                 "valid_fraction": stats["keypoints_valid"] / (world * args.keypoints),
                 "stage_ms": stage_ms, "roofline": roof}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:                # the CPU side-by-side belongs to the one-GPU line only
             frames = [f.cpu().numpy() for f in wl.frames[:5]]
             line["cpu_baseline"] = cpu_baseline(args, frames)
-        if not args.no_frame_loop:
+        if not args.no_frame_loop and world == 1:         # extra legs: one GPU, while no other rank waits
             line["frame_loop"] = frame_loop_leg(ctx, not args.no_cpu)
         print(json.dumps(line))
     dist.barrier()
