@@ -215,12 +215,15 @@ class _Loader:
 
 
 class dataLoaderKitti(_Loader):
-    def __init__(self, path, last_frame=4540):
+    """utils/dataLoaderKitti.m reads sequence 00 only (:21,47); `sequence` lets the sharded runner take the others
+    (BASELINE configs[4]); K stays the reference's sequence-00 matrix unless `K` is given."""
+
+    def __init__(self, path, last_frame=4540, sequence="00", K=None):
         super().__init__(path)
-        self.camParams = CameraParams(KITTI_K)
-        self.ground_truth_data = _load_ground_truth(os.path.join(self.dataset_path, "poses", "00.txt"))
+        self.camParams = CameraParams(KITTI_K if K is None else K)
+        self.ground_truth_data = _load_ground_truth(os.path.join(self.dataset_path, "poses", "%s.txt" % sequence))
         self.last_frame = int(last_frame)                            # dataLoaderKitti.m:49
-        self.img_file_format = os.path.join(self.dataset_path, "00", "image_0", "%06d.png")
+        self.img_file_format = os.path.join(self.dataset_path, sequence, "image_0", "%06d.png")
 
     def _path(self, index):
         return self.img_file_format % index
