@@ -110,6 +110,11 @@ int vo_ctx_read_counters(vo_ctx* ctx, uint64_t out[4], int reset);
 /* HIP-event stopwatch on the ctx stream (bench.py's live kernel timing) */
 int vo_timer_start(vo_ctx* ctx);
 int vo_timer_stop_ms(vo_ctx* ctx, float* ms);
+/* many intervals on the ctx stream read back with one synchronisation: begin / end bracket a lap without
+ * waiting; vo_timer_laps_ms waits for the last lap, returns the sum of all laps and their number, and resets */
+int vo_timer_lap_begin(vo_ctx* ctx);
+int vo_timer_lap_end(vo_ctx* ctx);
+int vo_timer_laps_ms(vo_ctx* ctx, float* total_ms, int* laps);
 
 /* ==== host-pointer entry points (what the MEX gateways bind) ==== */
 

@@ -59,6 +59,7 @@ class FrameInfo(C.Structure):
 EXPORTS = [
     "vo_strerror", "vo_version", "vo_ctx_create", "vo_ctx_destroy", "vo_ctx_set_stream", "vo_ctx_get_stream",
     "vo_ctx_sync", "vo_ctx_last_error", "vo_ctx_read_counters", "vo_timer_start", "vo_timer_stop_ms",
+    "vo_timer_lap_begin", "vo_timer_lap_end", "vo_timer_laps_ms",
     "vo_klt_track", "vo_select_candidates", "vo_harris_response", "vo_corner_response",
     "vo_select_keypoints_greedy", "vo_triangulate_candidates", "vo_angle_deg", "vo_in_front", "vo_reproj_error",
     "vo_p3p_ransac", "vo_p3p_batch", "vo_essential_ransac", "vo_dev_frame_build", "vo_dev_klt_track", "vo_dev_select_candidates", "vo_dev_select_begin", "vo_dev_select_finish",
@@ -161,6 +162,18 @@ class Context:
         ms = C.c_float()
         self.call("vo_timer_stop_ms", C.byref(ms))
         return ms.value
+
+    def lap_begin(self):
+        self.call("vo_timer_lap_begin")
+
+    def lap_end(self):
+        self.call("vo_timer_lap_end")
+
+    def laps_ms(self):
+        """-> (sum of the laps in ms, number of laps); one synchronisation, then reset."""
+        ms, n = C.c_float(), C.c_int()
+        self.call("vo_timer_laps_ms", C.byref(ms), C.byref(n))
+        return ms.value, n.value
 
     def close(self):
         if self.h:

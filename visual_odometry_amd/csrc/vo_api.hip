@@ -78,6 +78,7 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->lap_ev) (void)hipEventDestroy(e);
     if (c->side) {
         (void)hipStreamSynchronize(c->side);
         (void)hipStreamDestroy(c->side);
@@ -125,6 +126,43 @@ int vo_timer_stop_ms(vo_ctx* ctx, float* ms) {
     VO_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     VO_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
     VO_HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return VO_OK;
+}
+
+// laps: many intervals on the ctx stream, read back with ONE synchronisation (the host never idles the GPU
+// between the intervals, so the kernels inside see the clocks of a saturated device)
+int vo_timer_lap_begin(vo_ctx* ctx) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    if (ctx->lap_open) { ctx->last_error = "vo_timer_lap_begin: the previous lap was not ended"; return VO_ERR_BAD_ARG; }
+    while ((int)ctx->lap_ev.size() < 2 * (ctx->laps + 1)) {
+        hipEvent_t e = nullptr;
+        VO_HIP_CHECK(ctx, hipEventCreate(&e));
+        ctx->lap_ev.push_back(e);
+    }
+    VO_HIP_CHECK(ctx, hipEventRecord(ctx->lap_ev[2 * ctx->laps], ctx->stream));
+    ctx->lap_open = true;
+    return VO_OK;
+}
+int vo_timer_lap_end(vo_ctx* ctx) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    if (!ctx->lap_open) { ctx->last_error = "vo_timer_lap_end: no lap was begun"; return VO_ERR_BAD_ARG; }
+    VO_HIP_CHECK(ctx, hipEventRecord(ctx->lap_ev[2 * ctx->laps + 1], ctx->stream));
+    ctx->lap_open = false;
+    ctx->laps += 1;
+    return VO_OK;
+}
+int vo_timer_laps_ms(vo_ctx* ctx, float* total_ms, int* laps) {
+    if (!ctx || !total_ms || !laps || ctx->lap_open) return VO_ERR_BAD_ARG;
+    float tot = 0.0f;
+    for (int i = 0; i < ctx->laps; ++i) {
+        float ms = 0.0f;
+        VO_HIP_CHECK(ctx, hipEventSynchronize(ctx->lap_ev[2 * i + 1]));
+        VO_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->lap_ev[2 * i], ctx->lap_ev[2 * i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *laps = ctx->laps;
+    ctx->laps = 0;
     return VO_OK;
 }
 

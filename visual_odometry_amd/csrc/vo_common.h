@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 #include "../../include/vo_hip.h"
 
 #define VO_MAX_LEVELS 8
@@ -36,6 +37,8 @@ struct vo_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> lap_ev;   // vo_timer_lap_*: begin / end events of the laps recorded so far
+    int laps = 0; bool lap_open = false;
     // side stream for work that depends on the new image only (corner detection) and runs beside tracking
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
