@@ -89,7 +89,7 @@ def frame_loop_leg(ctx, with_cpu, n_frames=24):
     dev = [torch.from_numpy(f).to(f"cuda:{ctx.device}") for f in frames]
     loop = FrameLoop(K, frames[0].shape, ctx=ctx)
     best = None
-    for _ in range(3):                                    # pass 0 warms the scratch buffers up
+    for _ in range(10):                                   # pass 0 warms the scratch buffers up, the others the clocks
         loop.set_state(st, dev[0])
         ctx.sync()
         t0 = time.perf_counter()
@@ -110,7 +110,7 @@ def frame_loop_leg(ctx, with_cpu, n_frames=24):
     st2.candidate_first_poses = np.zeros((0, 4, 3))
     loop2 = FrameLoop(K, frames[0].shape, maxNumLandmarks=2000, CandidatesToKeep=300, ctx=ctx)
     best2 = None
-    for _ in range(3):
+    for _ in range(10):
         loop2.set_state(st2, dev[0])
         ctx.sync()
         t0 = time.perf_counter()
