@@ -212,7 +212,8 @@ def to_gray(img):
 # N12: baseline JPEG.  The stream is ITU-T T.81 (public standard); the arithmetic after the entropy decoder
 # is not fixed by the standard, so it is DEFINED here, as the common integer decoders do it, and pinned by
 # the CPU tests against Pillow's decoder (byte for byte on files of every sampling / quality tried):
-#   dequantise: coefficient * table entry (int);
+#   dequantise: coefficient * table entry (int; the product and the IDCT's sums never leave 32 bits for a
+#     valid stream -- the native code lets them wrap for a damaged one, this restatement does not model that);
 #   inverse DCT: Loeffler-Ligtenberg-Moschytz 8-point, 13-bit constants, columns first with the result
 #     rounded to 2 extra bits ((x + 1024) >> 11), then rows ((x + 131072) >> 18), + 128, range-limited
 #     through a 1024-entry wrap (x & 1023 -> 0..255);

@@ -105,10 +105,10 @@ __global__ void __launch_bounds__(256) k_jpeg_idct(const int16_t* __restrict__ c
         const int16_t* blk = coef + (size_t)b * 64;
         int in[8], o[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) in[r] = (int)blk[r * 8 + j] * (int)a.qt[c][r * 8 + j];
+        for (int r = 0; r < 8; ++r) in[r] = vo_jpeg_dequant(blk[r * 8 + j], a.qt[c][r * 8 + j]);
         vo_jpeg_idct8(in, o);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) w[r * 9 + j] = (o[r] + 1024) >> 11;
+        for (int r = 0; r < 8; ++r) w[r * 9 + j] = vo_jpeg_descale(o[r], 11);
     }
     __syncthreads();
     if (!live) return;
@@ -119,8 +119,8 @@ __global__ void __launch_bounds__(256) k_jpeg_idct(const int16_t* __restrict__ c
     uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        lo |= (uint32_t)vo_jpeg_range((o[k] + 131072) >> 18) << (8 * k);
-        hi |= (uint32_t)vo_jpeg_range((o[k + 4] + 131072) >> 18) << (8 * k);
+        lo |= (uint32_t)vo_jpeg_range(vo_jpeg_descale(o[k], 18)) << (8 * k);
+        hi |= (uint32_t)vo_jpeg_range(vo_jpeg_descale(o[k + 4], 18)) << (8 * k);
     }
     const unsigned rel = b - a.block0[c];
     const unsigned by = rel / (unsigned)a.bw[c], bx = rel - by * (unsigned)a.bw[c];

@@ -376,15 +376,15 @@ void vo_jpeg_reconstruct(const JpegFrame& f, const int16_t* coef, uint8_t* out, 
                 int ws[64];
                 for (int col = 0; col < 8; ++col) {  // columns first
                     int in[8], o[8];
-                    for (int r = 0; r < 8; ++r) in[r] = blk[r * 8 + col] * q[r * 8 + col];
+                    for (int r = 0; r < 8; ++r) in[r] = vo_jpeg_dequant(blk[r * 8 + col], q[r * 8 + col]);
                     vo_jpeg_idct8(in, o);
-                    for (int r = 0; r < 8; ++r) ws[r * 8 + col] = (o[r] + 1024) >> 11;
+                    for (int r = 0; r < 8; ++r) ws[r * 8 + col] = vo_jpeg_descale(o[r], 11);
                 }
                 for (int r = 0; r < 8; ++r) {
                     int o[8];
                     vo_jpeg_idct8(ws + r * 8, o);
                     uint8_t* dst = pl + (size_t)(by * 8 + r) * pitch + bx * 8;
-                    for (int col = 0; col < 8; ++col) dst[col] = (uint8_t)vo_jpeg_range((o[col] + 131072) >> 18);
+                    for (int col = 0; col < 8; ++col) dst[col] = (uint8_t)vo_jpeg_range(vo_jpeg_descale(o[col], 18));
                 }
             }
     }

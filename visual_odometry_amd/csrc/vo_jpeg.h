@@ -50,44 +50,53 @@ VO_JPEG_FN int vo_jpeg_range(int x) {
 }
 
 // one 8-point pass of the 13-bit fixed-point Loeffler-Ligtenberg-Moschytz inverse DCT; o[k] are the
-// un-descaled sums (the caller shifts: 11 bits after the column pass, 18 after the row pass)
+// un-descaled sums (the caller descales: 11 bits after the column pass, 18 after the row pass).  The sums are
+// formed in 32-bit two's-complement arithmetic that wraps (unsigned), so a damaged file's out-of-range
+// coefficients give some defined pixel values instead of a signed overflow; a valid file never wraps.
 VO_JPEG_FN void vo_jpeg_idct8(const int in[8], int o[8]) {
-    int z2 = in[2], z3 = in[6];
-    int z1 = (z2 + z3) * 4433;
-    const int t2 = z1 + z3 * (-15137), t3 = z1 + z2 * 6270;
-    z2 = in[0];
-    z3 = in[4];
-    const int t0 = (z2 + z3) * 8192, t1 = (z2 - z3) * 8192;
-    const int t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
-    int o0 = in[7], o1 = in[5], o2 = in[3], o3 = in[1];
+    typedef uint32_t U;
+    U z2 = (U)in[2], z3 = (U)in[6];
+    U z1 = (z2 + z3) * (U)4433;
+    const U t2 = z1 + z3 * (U)-15137, t3 = z1 + z2 * (U)6270;
+    z2 = (U)in[0];
+    z3 = (U)in[4];
+    const U t0 = (z2 + z3) * (U)8192, t1 = (z2 - z3) * (U)8192;
+    const U t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    U o0 = (U)in[7], o1 = (U)in[5], o2 = (U)in[3], o3 = (U)in[1];
     z1 = o0 + o3;
     z2 = o1 + o2;
     z3 = o0 + o2;
-    int z4 = o1 + o3;
-    const int z5 = (z3 + z4) * 9633;
-    o0 *= 2446;
-    o1 *= 16819;
-    o2 *= 25172;
-    o3 *= 12299;
-    z1 *= -7373;
-    z2 *= -20995;
-    z3 *= -16069;
-    z4 *= -3196;
+    U z4 = o1 + o3;
+    const U z5 = (z3 + z4) * (U)9633;
+    o0 *= (U)2446;
+    o1 *= (U)16819;
+    o2 *= (U)25172;
+    o3 *= (U)12299;
+    z1 *= (U)-7373;
+    z2 *= (U)-20995;
+    z3 *= (U)-16069;
+    z4 *= (U)-3196;
     z3 += z5;
     z4 += z5;
     o0 += z1 + z3;
     o1 += z2 + z4;
     o2 += z2 + z3;
     o3 += z1 + z4;
-    o[0] = t10 + o3;
-    o[7] = t10 - o3;
-    o[1] = t11 + o2;
-    o[6] = t11 - o2;
-    o[2] = t12 + o1;
-    o[5] = t12 - o1;
-    o[3] = t13 + o0;
-    o[4] = t13 - o0;
+    o[0] = (int)(t10 + o3);
+    o[7] = (int)(t10 - o3);
+    o[1] = (int)(t11 + o2);
+    o[6] = (int)(t11 - o2);
+    o[2] = (int)(t12 + o1);
+    o[5] = (int)(t12 - o1);
+    o[3] = (int)(t13 + o0);
+    o[4] = (int)(t13 - o0);
 }
+
+// round-to-nearest right shift of such a sum (the rounding add wraps like the sums do)
+VO_JPEG_FN int vo_jpeg_descale(int x, int bits) { return (int)((uint32_t)x + (1u << (bits - 1))) >> bits; }
+
+// a coefficient times its quantiser step, wrapped the same way
+VO_JPEG_FN int vo_jpeg_dequant(int c, int q) { return (int)((uint32_t)c * (uint32_t)q); }
 
 // YCbCr -> RGB with 16-bit fixed-point coefficients (1.402, 0.34414, 0.71414, 1.772), rounded to nearest
 VO_JPEG_FN void vo_jpeg_ycc(int y, int cb, int cr, int* r, int* g, int* b) {
