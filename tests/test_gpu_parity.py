@@ -126,6 +126,68 @@ def test_klt_images_smaller_than_the_patch(ctx, nv, nu):
         assert np.hypot(qu - ou, qv - ov)[both].max() < PX_TOL
 
 
+def test_klt_points_outside_the_image_or_not_finite(ctx):
+    """A caller may hand over anything: NaN, infinities, positions outside the image, positions exactly on
+    the border.  Such points come back invalid (as the oracle has them: N4's lost test / flat exit), nothing
+    faults, and the good points beside them get the bits they get without them."""
+    nv, nu = 150, 210
+    img1, img2, _ = synth.frame_pair(nv=nv, nu=nu, seed=15, shift=(1.2, -0.7))
+    gu, gv = synth.keypoints(60, nv=nv, nu=nu, seed=16, border=25.0)
+    odd = [np.nan, np.inf, -np.inf, -0.5, -30.0, nu - 0.75, nu + 40.0, 1e12, -1e12, 3e38, 0.0, float(nu - 1)]
+    bu = np.array(odd + [50.0] * len(odd))
+    bv = np.array([40.0] * len(odd) + [np.nan, np.inf, -np.inf, -0.5, -30.0, nv - 0.75, nv + 40.0, 1e12, -1e12, 3e38, 0.0,
+                                       float(nv - 1)])
+    pu = np.concatenate([gu[:30], bu, gu[30:]]); pv = np.concatenate([gv[:30], bv, gv[30:]])
+    bad = np.zeros(len(pu), bool); bad[30:30 + len(bu)] = True
+    for wu, wv, levels in ((31, 31, 3), (41, 41, 4), (7, 7, 2)):
+        for cm in (False, True):
+            qu, qv, valid, score = klt_gpu(img1, img2, pu, pv, levels, wu, wv, 30, 1.5, cm)
+            ou, ov, ovalid, oscore, *_ = oracle.klt_track(img1, img2, pu, pv, levels=levels, max_bidir=1.5, wu=wu, wv=wv,
+                                                          max_iters=30)
+            outside = bad & ~((pu >= 0) & (pu <= nu - 1) & (pv >= 0) & (pv <= nv - 1))
+            assert outside.sum() == 20 and not valid[outside].any() and not ovalid[outside].any()
+            assert np.array_equal(valid, ovalid)
+            both = valid & ovalid
+            assert both[~bad].sum() > 40 and np.hypot(qu[both] - ou[both], qv[both] - ov[both]).max() < PX_TOL
+            cu, cv, cvalid, cscore = klt_gpu(img1, img2, gu, gv, levels, wu, wv, 30, 1.5, cm)
+            assert np.array_equal(qu[~bad], cu) and np.array_equal(qv[~bad], cv) and np.array_equal(valid[~bad], cvalid)
+            assert np.array_equal(score[~bad], cscore)
+
+
+@pytest.mark.parametrize("nv,nu", [(8, 8), (8, 60), (90, 8), (9, 11)])
+def test_klt_smallest_images(ctx, nv, nu):
+    """The smallest shapes the entry point takes (8 x 8, top level at least 2 x 2); beyond that it is an error."""
+    img1, img2, _ = synth.frame_pair(nv=nv, nu=nu, seed=19, shift=(0.4, 0.3), margin=8)
+    pu, pv = synth.keypoints(40, nv=nv, nu=nu, seed=20, border=0.0)
+    qu, qv, valid, score = klt_gpu(img1, img2, pu, pv, 3, 7, 7, 30, 2.0)
+    ou, ov, ovalid, oscore, *_ = oracle.klt_track(img1, img2, pu, pv, levels=3, max_bidir=2.0, wu=7, wv=7, max_iters=30)
+    assert (valid == ovalid).mean() >= 0.9
+    both = valid & ovalid
+    if both.any():
+        assert np.hypot(qu[both] - ou[both], qv[both] - ov[both]).max() < PX_TOL
+    with pytest.raises(Exception):
+        ops.klt_track(img1[:7], img2[:7], np.ones((3, 2)))
+    if min(nv, nu) == 8:
+        with pytest.raises(Exception):                      # 8 -> 4 -> 2 -> 1: the fourth level is below 2 x 2
+            ops.klt_track(img1, img2, np.ones((3, 2)), 4)
+
+
+def test_selection_existing_points_outside_the_image_or_not_finite(ctx):
+    """Existing keypoints of any value: the distance filter's grid clamps them into its border cells (NaN into
+    cell 0); the verdict stays the oracle's all-pairs one, bit for bit."""
+    img, _, _ = synth.frame_pair(nv=150, nu=210, seed=17, noise=1.0)
+    eu, ev = synth.keypoints(300, nv=150, nu=210, seed=18, border=0.0)
+    odd = np.array([np.nan, np.inf, -np.inf, -3.0, -1e9, 212.5, 1e9, 3e38, 0.0, 209.0], np.float32)
+    eu = np.concatenate([eu.astype(np.float32), odd, np.full(len(odd), 100, np.float32)])
+    ev = np.concatenate([ev.astype(np.float32), np.full(len(odd), 70, np.float32), odd])
+    for cm in (False, True):
+        u, v, lin, met = sel_gpu(img, eu, ev, cm, min_distance=7.0, min_quality=0.001, filter_size=5, keep=60)
+        ru, rv, rlin, rmet = oracle.select_candidates(img, eu, ev, 7.0, 0.001, 5, 60, col_major=cm)
+        np.testing.assert_array_equal(lin, rlin)
+        np.testing.assert_array_equal(u, ru); np.testing.assert_array_equal(v, rv)
+        assert len(lin) > 10
+
+
 @pytest.mark.parametrize("nv,nu,n", [(600, 800, 2000), (768, 1024, 5000)])
 def test_klt_malaga_shapes(ctx, nv, nu, n):
     """BASELINE configs on the Malaga shapes (utils/dataLoaderMalaga.m:54-55 loads 800 x 600; BASELINE

@@ -141,6 +141,12 @@ __device__ __forceinline__ void stage(float* patch, const float* __restrict__ im
 #if defined(__HIP_DEVICE_COMPILE__) // the host pass cannot type-check the 16-byte LDS-DMA builtin
     __syncthreads();
     lds_float* lp = reinterpret_cast<lds_float*>(reinterpret_cast<uintptr_t>(patch));
+    // A caller's keypoint may be anything (infinite, 1e12: the float -> int conversion saturates and the
+    // window offsets then wrap).  Beyond +-2^24 every patch is the replicated border anyway, so the origin
+    // is pinned there (scalar min / max) and none of the sums below can overflow.
+    constexpr int FAR = 1 << 24;
+    ou = clampi(ou, -FAR, FAR);
+    ov = clampi(ov, -FAR, FAR);
     if (ou >= 0 && ou + C::PW <= nu) {
         // Columns inside the image (wave-uniform): 16-byte LDS-DMA.  The LDS image is lane-linear per
         // instruction (base + lane * 16), so with PW a multiple of 4 lanes (lr, lq) = (lane / NQ, lane % NQ)
@@ -204,6 +210,13 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     const int nu0 = a.nu0, nv0 = a.nv0;
     double gu = 0, gv = 0;
     int flags = 0;
+    // A start that is not finite or is absurdly far away is lost before anything is staged: every path below
+    // would end there too (flat at every level or the first lost test, displacement 0), and from here on all
+    // positions are bounded -- the start by this test, each step by the lost test before a B patch is staged.
+    if (!(fabs(su) <= 4194304.0 && fabs(sv) <= 4194304.0)) {
+        qu = su; qv = sv; ssd_out = 0.0f;
+        return 1;
+    }
     bool staged0 = false; // level 0: is a B patch staged, and where (re-used by the score)
     int pou0 = 0, pov0 = 0;
     for (int l = a.levels - 1; l >= 0; --l) {
