@@ -99,3 +99,48 @@ def test_a_pool_closed_early_stops_its_workers(ctx, tmp_path):
     assert threading.active_count() == t0
     assert psutil.Process().num_threads() <= n0 + 2     # the native workers (4 per pool) are joined at close
     assert device_used() - d0 <= (4 << 20)
+
+
+def test_two_contexts_on_two_threads(ctx):
+    """include/vo_hip.h: one vo_ctx per thread.  Two host threads, each with a context of its own, run the path's
+    entry points at the same time (ctypes drops the GIL inside the calls) and get the bits a lone call gets."""
+    import threading
+    img1, img2, _ = synth.frame_pair(nv=240, nu=320, seed=55, shift=(0.9, -0.8))
+    pu, pv = synth.keypoints(3000, nv=240, nu=320, seed=56)
+    pts = np.stack([pu, pv], 1)
+    rng = np.random.default_rng(57)
+    Kc = np.array([[300.0, 0, 160], [0, 300.0, 120], [0, 0, 1]])
+    X = np.column_stack([rng.uniform(-2, 2, 800), rng.uniform(-1.5, 1.5, 800), rng.uniform(4, 9, 800)])
+    uvw = X @ Kc.T
+    xy = uvw[:, :2] / uvw[:, 2:] + rng.normal(0, 0.3, (800, 2))
+    xy[::5] += rng.uniform(-40, 40, (160, 2))
+
+    def work(c):
+        a = ops.klt_track(img1, img2, pts, 3, 2.0, (31, 31), 30, index_base=0, ctx=c)
+        b = ops.select_candidates(img2, pts[:500], keep=80, index_base=0, want_all=True, ctx=c)
+        r = ops.p3p_ransac(xy, X, Kc, num_hyp=600, seed=9, ctx=c)
+        assert r["status"] == 0 and r["num_inliers"] > 400
+        return list(a) + list(b) + [r["R"], r["t"], r["inliers"], np.array([r["best_hyp"], r["best_sol"], r["trials"]])]
+
+    ref = work(ctx)
+    results, errors = {}, []
+
+    def runner(k):
+        c = _lib.Context(0)
+        try:
+            for _ in range(6):
+                out = work(c)
+            results[k] = out
+        except Exception as e:                                 # surfaced below: a thread's exception is not pytest's
+            errors.append(e)
+        finally:
+            c.close()
+
+    threads = [threading.Thread(target=runner, args=(k,)) for k in range(2)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors
+    for k in range(2):
+        assert len(results[k]) == len(ref)
+        for got, exp in zip(results[k], ref):
+            assert np.array_equal(got, exp, equal_nan=True)

@@ -43,6 +43,7 @@ struct vo_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     struct vo_sel_pending* sel_pending = nullptr;  // vo_dev_select_begin .. vo_dev_select_finish
+    bool resp_attr_set = false;  // k_response's dynamic-LDS limit raised on this context's device (a per-device attribute)
     vo_pyr frames[VO_NUM_FRAME_SLOTS];
     uint64_t clock = 0;
     unsigned long long* d_counters = nullptr; // VO_COUNTER_SHARDS x 4 u64

@@ -589,10 +589,9 @@ int vo_launch_response(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_img, in
     size_t lds = ((size_t)(SW * SH + 15) & ~(size_t)15) + sizeof(int32_t) * (3 * (size_t)PW * PH + 3 * (size_t)RS_TU * PH);
     if (d_maxbits) VO_HIP_CHECK(ctx, hipMemsetAsync(d_maxbits, 0, sizeof(unsigned long long), stream));
     dim3 grid((nu + RS_TU - 1) / RS_TU, (nv + RS_TV - 1) / RS_TV);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_response, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
+    if (!ctx->resp_attr_set) {
+        VO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_response, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        ctx->resp_attr_set = true;
     }
     hipLaunchKernelGGL(k_response, grid, dim3(256), lds, stream, a);
     VO_HIP_CHECK(ctx, hipGetLastError());
