@@ -256,21 +256,8 @@ def main():
         respin = 60
         for _ in range(respin): # untimed: the statistics collective above left the device idle for a moment and the
             wl.step()           # clocks take ~25 steps to come back (the kernel runs 1.1 ms right after, 0.86 steady)
-        for _ in range(reps):   # whole steps with a lap around the KLT launch.  The selection is the single call
-            k = wl.k            # here: with its image-only half forked beside (as in the timed region) the lap would
-            a, b = k % 2, (k + 1) % 2      # also count the time k_lk queues behind that side-stream work
-            nxt = (k % wl.n_frames) + 1
-            wl.build(b, nxt)
-            ctx.lap_begin()
-            wl.track_all(a, b)
-            ctx.lap_end()
-            if wl.nl >= 4:
-                wl.pose()
-            wl.triangulate()
-            wl.select(nxt)
-            wl.k += 1
-            if wl.k % wl.n_frames == 0:
-                wl.build(wl.k % 2, 0)
+        for _ in range(reps):   # whole steps with a lap around the KLT launch (nothing runs beside it: the work
+            wl.step(lap=True)   # issued ahead starts behind the tracking launch, see FrameWorkload.step_ahead)
         ms, nlaps = ctx.laps_ms()                         # one synchronisation for all laps
         ms /= nlaps
         wl.sync()
@@ -292,6 +279,7 @@ def main():
                         "launch_ms = HIP events around the KLT launch inside whole frame steps, read back once at the end; "
                         "traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch from profiles/round1_k_lk_pmc.json "
                         "(fabric-side, Infinity-Cache hits included; FETCH_SIZE doubled for the 16-B/lane loads)"}
+        wl.drain()              # single stages from here on: finish what was begun ahead
         a, b = wl.k % 2, (wl.k + 1) % 2
         for name, fn in (("pyramid", lambda: wl.build(b, (wl.k % wl.n_frames) + 1)), ("klt_landmarks+candidates", lambda: wl.track_all(a, b)),
                          ("ransac", wl.pose), ("triangulate", wl.triangulate), ("select", lambda: wl.select(1))):

@@ -214,11 +214,24 @@ int vo_dev_select_candidates(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, 
  * regional maxima: modules/selectCandidateKeypoints.m:20) runs on a side stream of the ctx beside whatever is
  * enqueued between them (tracking, pose, triangulation), and only the part that needs the existing points
  * (:23-33) runs where vo_dev_select_candidates would.  Results are identical to the single call.
- * max_exist: upper bound of the n_exist that vo_dev_select_finish will pass.  One selection at a time. */
+ * max_exist: upper bound of the n_exist that vo_dev_select_finish will pass.  At most two selections may be
+ * open; vo_dev_select_finish finishes the oldest.  d_img must stay untouched until that finish has run. */
 int vo_dev_select_begin(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, const vo_sel_opts* opts, int max_exist);
 int vo_dev_select_finish(vo_ctx* ctx, int u_is_rows, const float* d_eu, const float* d_ev, int n_exist,
                          float* d_out_u, float* d_out_v, int32_t* d_out_lin, double* d_out_metric,
                          int32_t* d_out_count);
+/* Everything about a frame that needs nothing but its image, issued ahead of the frame's turn: the pyramid of
+ * `slot` (what vo_dev_frame_build computes) and, with opts != NULL, the first half of a selection on the image
+ * (what vo_dev_select_begin computes; it joins the same queue, finish it with vo_dev_select_finish).  The work
+ * runs on the ctx's side stream once everything enqueued on the ctx stream so far has run, i.e. beside whatever
+ * is enqueued next: called right after frame k's tracking call for frame k+2's image, it fills the thinly
+ * occupied tail of frame k's step (pose, triangulation, selection filter) instead of standing in front of frame
+ * k+1's tracking.  The ctx stream waits for the pyramid at the first vo_dev_klt_track (or vo_dev_frame_build)
+ * that names the slot; vo_ctx_sync waits for the side stream too.  The slot must not be one that work enqueued
+ * later reads before that wait (three slots rotate; the reference has no counterpart: MATLAB runs imread,
+ * the tracker and detectMinEigenFeatures one after the other, main.m:52-59). */
+int vo_dev_frame_prefetch(vo_ctx* ctx, int slot, const uint8_t* d_img, int nu, int nv, int levels,
+                          const vo_sel_opts* opts, int max_exist);
 /* row-major device arrays: xy C x 2, poses P x 12, X C x 3 */
 int vo_dev_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, const double* d_poses0,
                        int P, const int32_t* d_pose_idx, int C, const double* d_pose1,

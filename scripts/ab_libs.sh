@@ -8,7 +8,8 @@ for r in $(seq 1 "$rounds"); do
     python - "$lib" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_tmp.json"))
-print(sys.argv[1], "ms_per_step %.4f" % d["ms_per_step"], "k_lk %.4f" % d["roofline"]["launch_ms"], flush=True)
+print(sys.argv[1], "ms_per_step %.4f" % d["ms_per_step"], "k_lk %.4f" % d["roofline"]["launch_ms"],
+      " ".join("%s %.4f" % (k.split("+")[0][:6], v) for k, v in d["stage_ms"].items()), flush=True)
 PY
   done
 done

@@ -8,13 +8,20 @@
 #include <vector>
 
 // scratch buffer purposes
-enum { SB_PU = 0, SB_PV, SB_QU, SB_QV, SB_VALID, SB_SCORE, SB_IMG, SB_A, SB_B, SB_C, SB_D, SB_E, SB_F, SB_G, SB_H, SB_I };
+enum { SB_PU = 0, SB_PV, SB_QU, SB_QV, SB_VALID, SB_SCORE, SB_IMG, SB_A, SB_B, SB_C, SB_D, SB_E, SB_F, SB_G, SB_H, SB_I,
+       SB_RGB = 16, SB_A2 = 17 };
 
-struct vo_sel_pending {  // vo_dev_select_begin .. vo_dev_select_finish
-    bool open = false;
-    int nu = 0, nv = 0, max_exist = 0;
-    vo_sel_opts o;
-    vo_sel_work w;
+// Selections begun and not yet finished (vo_dev_select_begin / vo_dev_frame_prefetch .. vo_dev_select_finish):
+// a queue of at most two, each with its own work buffers (set 0: scratch[SB_A], set 1: scratch[SB_A2]) and its
+// own join event, finished oldest first.
+struct vo_sel_pending {
+    struct Entry {
+        int nu = 0, nv = 0, max_exist = 0;
+        vo_sel_opts o;
+        vo_sel_work w;
+        hipEvent_t join = nullptr;  // recorded on the side stream behind the detect half
+    } q[2];
+    int head = 0, count = 0;        // q[head] is the oldest open entry
 };
 
 const char* vo_strerror(int code) {
@@ -70,9 +77,11 @@ void vo_ctx_destroy(vo_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->side) (void)hipStreamSynchronize(c->side);
     for (auto& f : c->frames) {
         if (f.I) (void)hipFree(f.I);
         if (f.img) (void)hipFree(f.img);
+        if (f.ready) (void)hipEventDestroy(f.ready);
     }
     for (auto& b : c->scratch) if (b.p) (void)hipFree(b.p);
     if (c->d_counters) (void)hipFree(c->d_counters);
@@ -85,6 +94,8 @@ void vo_ctx_destroy(vo_ctx* c) {
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->sel_pending)
+        for (auto& e : c->sel_pending->q) if (e.join) (void)hipEventDestroy(e.join);
     delete c->sel_pending;
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -100,6 +111,7 @@ void* vo_ctx_get_stream(vo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr
 int vo_ctx_sync(vo_ctx* ctx) {
     if (!ctx) return VO_ERR_BAD_ARG;
     VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->side) VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->side));   // work begun ahead (prefetch, detect half)
     return VO_OK;
 }
 const char* vo_ctx_last_error(vo_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
@@ -188,16 +200,56 @@ static int frame_prepare(vo_ctx* ctx, vo_pyr* f, int nu, int nv, int levels) {
     return VO_OK;
 }
 
+// the ctx stream waits, once, for a pyramid that vo_dev_frame_prefetch is building on the side stream
+static int frame_await(vo_ctx* ctx, vo_pyr* f) {
+    if (f->ready_pending) {
+        VO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, f->ready, 0));
+        f->ready_pending = false;
+    }
+    return VO_OK;
+}
+
 int vo_dev_frame_build(vo_ctx* ctx, int slot, const uint8_t* d_img, int nu, int nv, int levels) {
     if (!ctx || !d_img || slot < 0 || slot >= VO_NUM_FRAME_SLOTS) return VO_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
     vo_pyr* f = &ctx->frames[slot];
     f->valid = false;
-    int rc = frame_prepare(ctx, f, nu, nv, levels);
+    int rc = frame_await(ctx, f);   // a prefetch into this slot still in flight: this build comes after it
+    if (rc) return rc;
+    rc = frame_prepare(ctx, f, nu, nv, levels);
     if (rc) return rc;
     rc = vo_launch_frame_build(ctx, f, d_img);
     if (rc) return rc;
     f->valid = true; f->key = 0; f->stamp = ++ctx->clock;
     return VO_OK;
+}
+
+static int select_begin_on_side(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, const vo_sel_opts* o, int max_exist);
+static int check_sel_opts(vo_ctx* ctx, const vo_sel_opts* o);
+
+int vo_dev_frame_prefetch(vo_ctx* ctx, int slot, const uint8_t* d_img, int nu, int nv, int levels, const vo_sel_opts* o,
+                          int max_exist) {
+    if (!ctx || !d_img || slot < 0 || slot >= VO_NUM_FRAME_SLOTS || max_exist < 0) return VO_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (o) {
+        int rc = check_sel_opts(ctx, o);
+        if (rc) return rc;
+        if (ctx->sel_pending && ctx->sel_pending->count == 2) {
+            ctx->last_error = "vo_dev_frame_prefetch: two selections are already open";
+            return VO_ERR_BAD_ARG;
+        }
+    }
+    vo_pyr* f = &ctx->frames[slot];
+    f->valid = false;
+    int rc = frame_prepare(ctx, f, nu, nv, levels);   // may grow the slot (synchronises the ctx stream when it does)
+    if (rc) return rc;
+    if (!f->ready) VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&f->ready, hipEventDisableTiming));
+    if ((rc = vo_int_side_fork(ctx))) return rc;      // behind every reader and writer of the slot enqueued so far
+    if ((rc = vo_launch_frame_build(ctx, f, d_img, ctx->side))) return rc;
+    VO_HIP_CHECK(ctx, hipEventRecord(f->ready, ctx->side));
+    f->ready_pending = true;
+    f->valid = true; f->key = 0; f->stamp = ++ctx->clock;
+    return o ? select_begin_on_side(ctx, d_img, nu, nv, o, max_exist) : VO_OK;
 }
 
 int vo_dev_klt_track(vo_ctx* ctx, int sa, int sb, const double* d_pu, const double* d_pv, int n, int wu, int wv,
@@ -208,6 +260,10 @@ int vo_dev_klt_track(vo_ctx* ctx, int sa, int sb, const double* d_pu, const doub
     if (n < 0 || !d_pu || !d_pv || !d_qu || !d_qv || !d_valid || !d_score) return VO_ERR_BAD_ARG;
     if (!ctx->frames[sa].valid || !ctx->frames[sb].valid) { ctx->last_error = "klt: frame slot not built"; return VO_ERR_BAD_ARG; }
     if (eps <= 0) eps = 0.01;
+    (void)hipSetDevice(ctx->device);
+    int rc = frame_await(ctx, &ctx->frames[sa]);
+    if (!rc) rc = frame_await(ctx, &ctx->frames[sb]);
+    if (rc) return rc;
     return vo_launch_klt(ctx, &ctx->frames[sa], &ctx->frames[sb], d_pu, d_pv, n, wu, wv, max_iters, eps, max_bidir,
                          d_qu, d_qv, d_valid, d_score, d_fb);
 }

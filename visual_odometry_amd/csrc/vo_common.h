@@ -24,6 +24,8 @@ struct vo_pyr {            // one frame slot: float pyramid, all levels contiguo
     size_t cap = 0;        // floats allocated
     uint8_t* img = nullptr; // device copy of the uint8 image (host API)
     size_t img_cap = 0;
+    hipEvent_t ready = nullptr;   // vo_dev_frame_prefetch: recorded on the side stream behind the pyramid build
+    bool ready_pending = false;   // the ctx stream has not waited for `ready` yet
 };
 
 struct vo_buf {            // grow-only device buffer
@@ -47,7 +49,7 @@ struct vo_ctx {
     vo_pyr frames[VO_NUM_FRAME_SLOTS];
     uint64_t clock = 0;
     unsigned long long* d_counters = nullptr; // VO_COUNTER_SHARDS x 4 u64
-    vo_buf scratch[17];                        // purpose-indexed scratch (see vo_api.hip; [16] = vo_rgb2gray staging)
+    vo_buf scratch[18];                        // purpose-indexed scratch (see vo_api.hip; [16] = vo_rgb2gray staging, [17] = second selection set)
     std::string last_error;
 };
 
@@ -63,7 +65,7 @@ struct vo_ctx {
 int vo_buf_reserve(vo_ctx* ctx, vo_buf* b, size_t bytes);
 
 // ---- launchers (each returns VO_OK or an error code; all asynchronous on ctx->stream) ----
-int vo_launch_frame_build(vo_ctx* ctx, vo_pyr* f, const uint8_t* d_img);
+int vo_launch_frame_build(vo_ctx* ctx, vo_pyr* f, const uint8_t* d_img, hipStream_t stream = nullptr);  // nullptr: ctx->stream
 int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d_pu, const double* d_pv, int n,
                   int wu, int wv, int max_iters, double eps, double max_bidir, double* d_qu, double* d_qv,
                   uint8_t* d_valid, float* d_score, float* d_fb);
@@ -125,5 +127,5 @@ int vo_launch_p3p_batch(vo_ctx* ctx, const double* d_P, const double* d_f, int n
 
 // ---- helpers of vo_api.hip shared with vo_frame.hip ----
 int vo_int_frame_prepare(vo_ctx* ctx, vo_pyr* f, int nu, int nv, int levels);
-int vo_int_sel_work_prepare(vo_ctx* ctx, int nu, int nv, int keep, int n_exist, double min_distance, vo_sel_work* w);
+int vo_int_sel_work_prepare(vo_ctx* ctx, int nu, int nv, int keep, int n_exist, double min_distance, vo_sel_work* w);  // set 0
 int vo_int_ransac_work_prepare(vo_ctx* ctx, int H, vo_ransac_work* w);

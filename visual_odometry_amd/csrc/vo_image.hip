@@ -57,12 +57,13 @@ __global__ __launch_bounds__(256) void k_pyr_down(const float* __restrict__ S, i
 
 } // namespace
 
-int vo_launch_frame_build(vo_ctx* ctx, vo_pyr* f, const uint8_t* d_img) {
+int vo_launch_frame_build(vo_ctx* ctx, vo_pyr* f, const uint8_t* d_img, hipStream_t stream) {
+    if (!stream) stream = ctx->stream;
     const long n = (long)f->nu * f->nv;
-    hipLaunchKernelGGL(k_level0, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, ctx->stream, d_img, n, f->I);
+    hipLaunchKernelGGL(k_level0, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, d_img, n, f->I);
     for (int l = 1; l < f->levels; ++l) {
         dim3 g((f->nus[l] + PD_TU - 1) / PD_TU, (f->nvs[l] + PD_TV - 1) / PD_TV);
-        hipLaunchKernelGGL(k_pyr_down, g, dim3(256), 0, ctx->stream, f->I + f->offs[l - 1], f->nus[l - 1],
+        hipLaunchKernelGGL(k_pyr_down, g, dim3(256), 0, stream, f->I + f->offs[l - 1], f->nus[l - 1],
                            f->nvs[l - 1], f->I + f->offs[l], f->nus[l], f->nvs[l]);
     }
     VO_HIP_CHECK(ctx, hipGetLastError());

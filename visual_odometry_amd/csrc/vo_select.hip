@@ -201,22 +201,24 @@ __global__ __launch_bounds__(DT_BLOCK) void k_detect(const double* __restrict__ 
 // exclusive scan of the per-block counts (single block), total -> *m0 (clamped to cap)
 __global__ __launch_bounds__(1024) void k_scan_counts(const int32_t* __restrict__ counts, int nblk, int32_t* offs,
                                                        int32_t* m0, int cap) {
-    __shared__ int part[1024];
-    const int t = threadIdx.x;
+    // exclusive prefix sums of `counts` (each thread owns `per` consecutive entries): wave scan by shuffles, the
+    // 16 wave totals through LDS
+    __shared__ int s_wave[16];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int per = (nblk + 1023) / 1024;
     int s = 0;
     for (int k = 0; k < per; ++k) { int i = t * per + k; if (i < nblk) s += counts[i]; }
-    part[t] = s;
+    int inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) s_wave[wid] = inc;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        int x = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += x;
-        __syncthreads();
-    }
-    int run = part[t] - s;
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int c = s_wave[w]; if (w < wid) before += c; total += c; }
+    int run = before + inc - s;
     for (int k = 0; k < per; ++k) { int i = t * per + k; if (i < nblk) { offs[i] = run; run += counts[i]; } }
-    if (t == 1023) *m0 = part[t] < cap ? part[t] : cap;
+    if (t == 0) *m0 = total < cap ? total : cap;
 }
 
 // ---- N8 distance filter: keep[i] = no existing point with d2 < thr_d2 (thr_d2 = smallest float
@@ -629,6 +631,11 @@ int vo_launch_select_detect(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_im
     hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, stream, w->resp, nu, nv, w->maxbits,
                        o->min_quality, 1, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric);
     VO_HIP_CHECK(ctx, hipMemsetAsync(w->m0 + 1, 0, sizeof(int32_t), stream)); // number of kept corners
+    // the distance filter's grid tables (count + cursor) start at zero; nothing but the grid size is needed for
+    // that, so it is done here, where the two-call forms run beside other work.  Rounded up to 16 bytes (one
+    // fill kernel instead of two; the arena pads every table by 256 bytes).
+    const size_t grid_bytes = (sizeof(int32_t) * 2 * (size_t)w->grid_gu * w->grid_gv + 15) & ~(size_t)15;
+    VO_HIP_CHECK(ctx, hipMemsetAsync(w->grid_count, 0, grid_bytes, stream));
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }
@@ -647,7 +654,7 @@ int vo_launch_select_filter(vo_ctx* ctx, hipStream_t stream, int nu, int nv, int
         g.eu = d_eu; g.ev = d_ev; g.ne = n_exist; g.ne_dev = ne_dev; g.inv_cs = 1.0f / w->grid_cs; g.gu = w->grid_gu; g.gv = w->grid_gv;
         g.count = w->grid_count; g.offs = w->grid_offs; g.cursor = w->grid_cursor; g.su = w->grid_su; g.sv = w->grid_sv;
         const int ncell = g.gu * g.gv;
-        VO_HIP_CHECK(ctx, hipMemsetAsync(g.count, 0, sizeof(int32_t) * 2 * (size_t)ncell, stream)); // count + cursor
+        // count + cursor were zeroed by the detect half (vo_launch_select_detect), off this stream's critical path
         const int eblk = (n_exist + 255) / 256;
         hipLaunchKernelGGL(k_grid_count, dim3(eblk), dim3(256), 0, stream, g);
         hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, g.count, ncell, g.offs, w->grid_total, 0x7fffffff);

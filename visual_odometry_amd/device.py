@@ -22,8 +22,11 @@ def _p(t):
 
 class FrameWorkload:
     def __init__(self, ctx, n_landmarks, n_candidates, nv=376, nu=1241, n_frames=16, num_hyp=2000, levels=4,
-                 block=41, max_iters=50, eps=0.01, max_bidir=2.0, keep=100, seed=1023, device=None):
+                 block=41, max_iters=50, eps=0.01, max_bidir=2.0, keep=100, seed=1023, device=None, ahead=None):
+        """ahead: the image-only work of a frame (pyramid, corner detection) is issued one step ahead on the side
+        stream (vo_dev_frame_prefetch); None: on unless VO_NO_PREFETCH is set (A/B switch for profiling)."""
         self.ctx = ctx
+        self.ahead = (not os.environ.get("VO_NO_PREFETCH")) if ahead is None else bool(ahead)
         self.dev = torch.device("cuda", ctx.device if device is None else device)
         self.nu, self.nv, self.levels, self.block = nu, nv, levels, block
         self.max_iters, self.eps, self.max_bidir = max_iters, eps, max_bidir
@@ -74,7 +77,11 @@ class FrameWorkload:
         self.sel_cnt = torch.zeros(1, dtype=torch.int32, device=self.dev)
         torch.cuda.synchronize(self.dev)
         self.k = 0
-        self.build(0, 0)
+        if self.ahead:
+            self.build(3, 0)           # frame 0 as "previous" of step 0
+            self.prefetch(0, 1)        # frame 1: what step 0 tracks into and selects on
+        else:
+            self.build(0, 0)
 
     # ---- single stages (asynchronous on the ctx stream) ----
     def build(self, slot, frame):
@@ -116,16 +123,58 @@ class FrameWorkload:
         self.ctx.call("vo_dev_select_finish", 0, _p(self.ex[0]), _p(self.ex[1]), self.n_exist, _p(self.sel_u), _p(self.sel_v),
                       _p(self.sel_lin), None, _p(self.sel_cnt))
 
-    def step(self):
-        """frame k (slot k%2, already built) -> frame k+1."""
+    def prefetch(self, slot, frame, select=True):
+        """pyramid of `frame` into `slot` (+ the detect half of the selection on it) on the side stream."""
+        self.ctx.call("vo_dev_frame_prefetch", slot, _p(self.frames[frame]), self.nu, self.nv, self.levels,
+                      C.byref(self.sel_opts) if select else None, self.n_exist)
+
+    def step_ahead(self, lap=False):
+        """One step with the next step's image-only work issued beside this step's tail.  Step k tracks frame
+        k % n -> k % n + 1; the new frame's pyramid sits in slot k % 3 (prefetched during step k-1), the previous
+        frame's in slot (k-1) % 3, or in slot 3 when the sequence has just wrapped round to frame 0."""
+        k, n = self.k, self.n_frames
+        a = 3 if k % n == 0 else (k - 1) % 3
+        b = k % 3
+        if lap:
+            self.ctx.lap_begin()
+        self.track_all(a, b)
+        if lap:
+            self.ctx.lap_end()
+        k1 = k + 1                       # the step after this one: its new frame, and frame 0 again if it wraps
+        self.prefetch(k1 % 3, (k1 % n) + 1)
+        if k1 % n == 0:
+            self.prefetch(3, 0, select=False)
+        if self.nl >= 4:
+            self.pose()
+        self.triangulate()
+        self.select_finish()             # the selection on this step's new frame, begun one step ago
+        self.k += 1
+
+    def drain(self):
+        """Finish what was begun ahead (the open selection), so that single stages can be called on their own."""
+        if self.ahead and self.k >= 0:
+            self.select_finish()
+            self.ahead = False
+            self.build(self.k % 2, self.k % self.n_frames)     # the serial steps' "previous" frame
+
+    def step(self, lap=False):
+        """frame k (slot k%2, already built) -> frame k+1.  lap: a vo_timer lap around the tracking launch."""
+        if self.ahead:
+            return self.step_ahead(lap)
         k = self.k
         a, b = k % 2, (k + 1) % 2
         nxt = (k % self.n_frames) + 1
-        two_phase = not os.environ.get("VO_SINGLE_CALL_SELECT")   # A/B switch for profiling
+        # the selection in two calls (its image-only half beside tracking) unless switched off for an A/B, or a lap
+        # is wanted: the lap would also count the time k_lk queues behind that side-stream work
+        two_phase = not os.environ.get("VO_SINGLE_CALL_SELECT") and not lap
         if two_phase:
             self.select_begin(nxt)     # corner detection on the new image runs beside the pyramid build and tracking
         self.build(b, nxt)
+        if lap:
+            self.ctx.lap_begin()
         self.track_all(a, b)       # landmarks + candidates in one launch
+        if lap:
+            self.ctx.lap_end()
         if self.nl >= 4:
             self.pose()
         self.triangulate()
