@@ -56,32 +56,41 @@ static void project(const double* cam, const double* X, double* u, double* v, do
     *u = pu / pw; *v = pv / pw; *w = pw;
 }
 
-/* smallest right-singular vector of a 4x4 matrix by one-sided (Hestenes) Jacobi, fixed 12 sweeps,
- * pair order (0,1)(0,2)(0,3)(1,2)(1,3)(2,3).  A is row-major and is overwritten. */
+/* one rotation of columns p, q of A (and of V) that makes them orthogonal; returns 1 unless it was the
+ * identity up to rounding (c == 1.0).  gamma == 0: c = 1, s = 0, applied like any other. */
+static int jacobi_rotate(double* A, double* V, int p, int q) {
+    double alpha = 0, beta = 0, gamma = 0;
+    for (int k = 0; k < 4; ++k) {
+        alpha += A[k * 4 + p] * A[k * 4 + p];
+        beta += A[k * 4 + q] * A[k * 4 + q];
+        gamma += A[k * 4 + p] * A[k * 4 + q];
+    }
+    double zeta = (beta - alpha) / (2.0 * gamma);
+    double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+    if (gamma == 0.0) { c = 1.0; s = 0.0; }
+    for (int k = 0; k < 4; ++k) {
+        double ap = A[k * 4 + p], aq = A[k * 4 + q];
+        A[k * 4 + p] = c * ap - s * aq; A[k * 4 + q] = s * ap + c * aq;
+        double vp = V[k * 4 + p], vq = V[k * 4 + q];
+        V[k * 4 + p] = c * vp - s * vq; V[k * 4 + q] = s * vp + c * vq;
+    }
+    return c != 1.0;
+}
+
+/* smallest right-singular vector of a 4x4 matrix by one-sided (Hestenes) Jacobi.  A sweep is three rounds of
+ * two disjoint column pairs, (0,1)(2,3) / (0,2)(1,3) / (0,3)(1,2) (the two rotations of a round touch different
+ * columns: the device runs them side by side); the iteration ends with the first sweep all of whose rotations
+ * were the identity up to rounding, after 12 sweeps at the latest.  A is row-major and is overwritten. */
 static void svd4_last(double* A, double* vout) {
+    static const int PAIRS[6][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {0, 3}, {1, 2}};
     double V[16];
     memset(V, 0, sizeof V);
     for (int i = 0; i < 4; ++i) V[i * 4 + i] = 1.0;
     for (int sweep = 0; sweep < 12; ++sweep) {
-        for (int p = 0; p < 3; ++p)
-            for (int q = p + 1; q < 4; ++q) {
-                double alpha = 0, beta = 0, gamma = 0;
-                for (int k = 0; k < 4; ++k) {
-                    alpha += A[k * 4 + p] * A[k * 4 + p];
-                    beta += A[k * 4 + q] * A[k * 4 + q];
-                    gamma += A[k * 4 + p] * A[k * 4 + q];
-                }
-                if (gamma == 0.0) continue;
-                double zeta = (beta - alpha) / (2.0 * gamma);
-                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-                for (int k = 0; k < 4; ++k) {
-                    double ap = A[k * 4 + p], aq = A[k * 4 + q];
-                    A[k * 4 + p] = c * ap - s * aq; A[k * 4 + q] = s * ap + c * aq;
-                    double vp = V[k * 4 + p], vq = V[k * 4 + q];
-                    V[k * 4 + p] = c * vp - s * vq; V[k * 4 + q] = s * vp + c * vq;
-                }
-            }
+        int rotated = 0;
+        for (int r = 0; r < 6; ++r) rotated |= jacobi_rotate(A, V, PAIRS[r][0], PAIRS[r][1]);
+        if (!rotated) break;
     }
     int best = 0; double bn = INFINITY;
     for (int j = 0; j < 4; ++j) {

@@ -50,36 +50,56 @@ __device__ __forceinline__ void project(const double* cam, const double* X, doub
     u = pu / pw; v = pv / pw; w = pw;
 }
 
-// one-sided Jacobi, 12 sweeps, same pair order as oracle/geom.c svd4_last.  Fully unrolled index
-// arithmetic keeps A and V in registers.
+// One-sided Jacobi as oracle/geom.c svd4_last defines it: a sweep is three rounds of two disjoint column pairs,
+// (0,1)(2,3) / (0,2)(1,3) / (0,3)(1,2); it ends with the first sweep all of whose rotations were the identity up
+// to rounding (c == 1.0), after 12 sweeps at the latest.  A thread's time here is one long chain of dependent
+// fp64 divisions and square roots: the two rotations of a round are written side by side so that their chains
+// interleave, and the early end halves the sweeps (5-6 instead of 12 on triangulation matrices).
+struct JRot { double c, s; };
+template <int P, int Q>
+__device__ __forceinline__ JRot jacobi_params(const double* A) {
+    double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        alpha += A[k * 4 + P] * A[k * 4 + P];
+        beta += A[k * 4 + Q] * A[k * 4 + Q];
+        gamma += A[k * 4 + P] * A[k * 4 + Q];
+    }
+    const double zeta = (beta - alpha) / (2.0 * gamma);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    JRot r;
+    r.c = 1.0 / sqrt(1.0 + t * t);
+    r.s = r.c * t;
+    if (gamma == 0.0) { r.c = 1.0; r.s = 0.0; }
+    return r;
+}
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_apply(double* A, double* V, const JRot r) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double ap = A[k * 4 + P], aq = A[k * 4 + Q];
+        A[k * 4 + P] = r.c * ap - r.s * aq; A[k * 4 + Q] = r.s * ap + r.c * aq;
+        const double vp = V[k * 4 + P], vq = V[k * 4 + Q];
+        V[k * 4 + P] = r.c * vp - r.s * vq; V[k * 4 + Q] = r.s * vp + r.c * vq;
+    }
+}
+template <int P0, int Q0, int P1, int Q1>
+__device__ __forceinline__ bool jacobi_round(double* A, double* V) {
+    const JRot r0 = jacobi_params<P0, Q0>(A), r1 = jacobi_params<P1, Q1>(A);   // disjoint columns: independent
+    jacobi_apply<P0, Q0>(A, V, r0);
+    jacobi_apply<P1, Q1>(A, V, r1);
+    return (r0.c != 1.0) | (r1.c != 1.0);
+}
+
 __device__ void svd4_last(double* A, double* vout) {
     double V[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 12; ++sweep) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = p + 1; q < 4; ++q) {
-                double alpha = 0, beta = 0, gamma = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    alpha += A[k * 4 + p] * A[k * 4 + p];
-                    beta += A[k * 4 + q] * A[k * 4 + q];
-                    gamma += A[k * 4 + p] * A[k * 4 + q];
-                }
-                if (gamma == 0.0) continue;
-                double zeta = (beta - alpha) / (2.0 * gamma);
-                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    double ap = A[k * 4 + p], aq = A[k * 4 + q];
-                    A[k * 4 + p] = c * ap - s * aq; A[k * 4 + q] = s * ap + c * aq;
-                    double vp = V[k * 4 + p], vq = V[k * 4 + q];
-                    V[k * 4 + p] = c * vp - s * vq; V[k * 4 + q] = s * vp + c * vq;
-                }
-            }
+        bool rotated = jacobi_round<0, 1, 2, 3>(A, V);
+        rotated |= jacobi_round<0, 2, 1, 3>(A, V);
+        rotated |= jacobi_round<0, 3, 1, 2>(A, V);
+        if (!rotated) break;
     }
     int best = 0; double bn = INFINITY;
 #pragma unroll
