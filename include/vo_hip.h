@@ -287,6 +287,14 @@ int vo_frame_set_image(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int 
 /* one processFrame: prev image = the last image given; returns the pose [R_WC; t_WC] and the counts */
 int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device, double pose43[12],
                      vo_frame_info* info);
+/* Look-ahead (optional; no counterpart in the reference, whose loop reads, tracks and detects one after the
+ * other, main.m:52-59).  Announce, before a vo_frame_process call, the image that the call AFTER it will
+ * process: that image's copy, pyramid and corner detection are then issued on the ctx's side stream behind the
+ * coming call's tracking launch, beside the thinly occupied rest of that frame, and the call that processes the
+ * announced image (same pointer, same on_device) only waits for them.  Results are identical with and without.
+ * The announced image must stay valid and unchanged until the call that processes it has returned; any other
+ * image given to that call, vo_frame_set_image or vo_frame_set_state abandon what was issued.  NULL withdraws. */
+int vo_frame_announce(vo_ctx* ctx, vo_frame_state* st, const uint8_t* next_img, int on_device);
 
 /* ==== frame ingest: imread + rgb2gray + im2uint8 as the reference's frame loops use
  * them (main.m:15-30,52-59; utils/dataLoaderKitti.m:29, utils/dataLoaderParking.m:29,
@@ -312,7 +320,8 @@ int vo_rgb2gray(vo_ctx* ctx, const uint8_t* rgb, int H, int W, int planar, int o
  * on a copy stream of the pool's own and convert colour images to gray there; vo_ingest_next returns the
  * frames in order as device images (H rows of W bytes, what vo_frame_process takes with on_device = 1)
  * and makes the ctx stream wait for the upload.  The image stays valid until the next vo_ingest_next /
- * vo_ingest_close on the same pool.  One consumer thread per pool. */
+ * vo_ingest_close on the same pool (with vo_ingest_set_hold(2): until the one after the next, which is what
+ * vo_frame_announce needs).  One consumer thread per pool. */
 typedef struct vo_ingest vo_ingest;
 typedef struct vo_ingest_opts {
     int threads;  /* decode threads; <= 0: min(8, host threads) */
@@ -327,6 +336,8 @@ int vo_ingest_next(vo_ingest* ing, const uint8_t** d_img, int* H, int* W, int* c
 /* copy the current frame (the one vo_ingest_next returned last) to the host; synchronises the ctx stream */
 int vo_ingest_read(vo_ingest* ing, uint8_t* host_out, size_t out_cap);
 /* summed wall time the workers spent reading + decoding + enqueueing, and the pool's actual sizes */
+/* how many of the images handed out stay valid (default 1); before the first vo_ingest_next, <= depth - 1 */
+int vo_ingest_set_hold(vo_ingest* ing, int hold);
 int vo_ingest_stats(vo_ingest* ing, double* decode_seconds_total, int* threads, int* depth);
 int vo_ingest_close(vo_ingest* ing);
 

@@ -183,3 +183,56 @@ def synth_lift_at(pose, u, v, depth=12.0):
     d = R.T @ (np.linalg.inv(K) @ np.stack([u, v, np.ones_like(u)]))
     lam = (depth - C[2]) / d[2]
     return (C[:, None] + lam * d).T
+
+
+def states_equal(a, b):
+    return all(np.array_equal(getattr(a, f), getattr(b, f)) for f in
+               ("landmarks", "keypoints", "reproError", "candidate_keypoints", "candidate_first_keypoints",
+                "candidate_first_poses", "candidate_time_indxs"))
+
+
+@pytest.mark.parametrize("device_images", [False, True])
+def test_look_ahead_changes_nothing_but_the_schedule(ctx, sequence, device_images):
+    """vo_frame_announce: every frame's successor announced (its pyramid and corner detection issued beside the
+    current frame's tail) against the plain loop: poses, counts and states are the same bits.  Then the cases that
+    abandon what was issued: another image than the announced one, a state load, a new previous image."""
+    frames, poses, lift = sequence
+    if device_images:
+        import torch
+        imgs = [torch.from_numpy(f).cuda() for f in frames]
+    else:
+        imgs = [np.ascontiguousarray(f) for f in frames]
+    st0 = start_state(frames[0], lift)
+
+    def run(announce):
+        loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=160, ctx=ctx)
+        loop.set_state(st0, imgs[0])
+        out = []
+        for k in range(1, len(imgs)):
+            nxt = announce(k)
+            p, status, info = loop.processFrame(imgs[k], nxt)
+            out.append((p, status, info, loop.get_state() if k % 4 == 0 else None))
+        final = loop.get_state()
+        loop.close()
+        return out, final
+
+    plain, plain_final = run(lambda k: None)
+    ahead, ahead_final = run(lambda k: imgs[k + 1] if k + 1 < len(imgs) else None)
+    # every third announcement names an image that is not the one processed next; another third announce nothing
+    wrong, wrong_final = run(lambda k: (imgs[0] if k % 3 == 0 else imgs[k + 1] if (k % 3 == 1 and k + 1 < len(imgs)) else None))
+    for other, other_final in ((ahead, ahead_final), (wrong, wrong_final)):
+        for (p0, s0, i0, g0), (p1, s1, i1, g1) in zip(plain, other):
+            assert np.array_equal(p0, p1) and s0 == s1 and i0 == i1
+            if g0 is not None:
+                assert states_equal(g0, g1)
+        assert states_equal(plain_final, other_final)
+    # a state load and a new previous image between the announcement and its use
+    loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=160, ctx=ctx)
+    loop.set_state(st0, imgs[0])
+    loop.processFrame(imgs[1], imgs[2])
+    loop.set_state(st0, imgs[0])                       # back to the start: what was issued for imgs[2] is dropped
+    p, status, info = loop.processFrame(imgs[1], imgs[2])
+    assert np.array_equal(p, plain[0][0]) and info == plain[0][2]
+    p, status, info = loop.processFrame(imgs[2])
+    assert np.array_equal(p, plain[1][0]) and info == plain[1][2]
+    loop.close()

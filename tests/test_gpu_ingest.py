@@ -206,3 +206,37 @@ def test_pool_jpeg_at_malaga_size_and_mixed_with_png(ctx, tmp_path):
             assert img.shape == want[k].shape, k
             assert np.array_equal(fs.read(), want[k]), k
         fs.close()
+
+
+def device_bytes(ctx, d):
+    """a DeviceImage's pixels on the host (hipMemcpy of the runtime the library is linked to)."""
+    import ctypes as C
+    ctx.sync()
+    out = np.empty(d.shape, np.uint8)
+    ctx.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert ctx.lib.hipMemcpy(_lib.ptr(out), C.c_void_p(d.data_ptr()), out.size, 2) == 0      # 2 = device to host
+    return out
+
+
+def test_two_frames_in_the_consumers_hands(ctx, tmp_path):
+    """hold = 2 (what FrameLoop.processFrame(curr, next) needs): the frame handed out before the current one stays
+    valid and unchanged while the pool decodes on; with more frames than slots every slot is reused."""
+    rng = np.random.default_rng(71)
+    imgs = [rng.integers(0, 256, (60, 80), dtype=np.uint8) for _ in range(12)]
+    paths = []
+    for i, im in enumerate(imgs):
+        p = tmp_path / ("h%02d.png" % i)
+        p.write_bytes(oi.png_encode(im))
+        paths.append(str(p))
+    fs = ingest.FrameStream(paths, threads=2, depth=3, hold=2)
+    prev = next(fs)
+    for k in range(1, len(imgs)):
+        cur = next(fs)
+        assert np.array_equal(fs.read(), imgs[k])                      # the current one, through the pool
+        assert np.array_equal(device_bytes(ctx, prev), imgs[k - 1]), k  # the one before it is still intact
+        assert np.array_equal(device_bytes(ctx, cur), imgs[k])
+        prev = cur
+    assert next(fs, None) is None
+    fs.close()
+    with pytest.raises(_lib.VoError):
+        ingest.FrameStream(paths, threads=1, depth=3, hold=3)          # hold <= depth - 1

@@ -397,7 +397,7 @@ int vo_int_side_join(vo_ctx* ctx) {
 }
 
 int vo_int_frame_prepare(vo_ctx* ctx, vo_pyr* f, int nu, int nv, int levels) { return frame_prepare(ctx, f, nu, nv, levels); }
-int vo_int_sel_work_prepare(vo_ctx* ctx, int nu, int nv, int keep, int n_exist, double min_distance, vo_sel_work* w) {
-    return sel_work_prepare(ctx, nu, nv, keep, n_exist, min_distance, w);
+int vo_int_sel_work_prepare(vo_ctx* ctx, int nu, int nv, int keep, int n_exist, double min_distance, vo_sel_work* w, int set) {
+    return sel_work_prepare(ctx, nu, nv, keep, n_exist, min_distance, w, set);
 }
 int vo_int_ransac_work_prepare(vo_ctx* ctx, int H, vo_ransac_work* w) { return ransac_work_prepare(ctx, H, w); }

@@ -127,5 +127,6 @@ int vo_launch_p3p_batch(vo_ctx* ctx, const double* d_P, const double* d_f, int n
 
 // ---- helpers of vo_api.hip shared with vo_frame.hip ----
 int vo_int_frame_prepare(vo_ctx* ctx, vo_pyr* f, int nu, int nv, int levels);
-int vo_int_sel_work_prepare(vo_ctx* ctx, int nu, int nv, int keep, int n_exist, double min_distance, vo_sel_work* w);  // set 0
+int vo_int_sel_work_prepare(vo_ctx* ctx, int nu, int nv, int keep, int n_exist, double min_distance, vo_sel_work* w,
+                            int set = 0);   // set: which of the ctx's two selection work areas
 int vo_int_ransac_work_prepare(vo_ctx* ctx, int H, vo_ransac_work* w);

@@ -328,9 +328,16 @@ __global__ void k_append_new(int32_t* counts, int capC, const float* su, const f
 struct vo_frame_state {
     vo_frame_opts o;
     int nu, nv, capL, capC, PW, ring, P;   // P = ring + upload pose slots
-    vo_pyr pyr[2];
-    uint8_t* img[2];
+    vo_pyr pyr[3];                          // previous image, the one being processed, the one announced after it
+    uint8_t* img[3];
     int cur;                                // slot holding the previous image
+    // look-ahead (vo_frame_announce): the announced image's copy, pyramid and detect half are issued on the side
+    // stream during the vo_frame_process call before its own, behind that call's tracking launch
+    const uint8_t* next_src = nullptr; int next_on_device = 0;    // announced, not issued yet
+    const uint8_t* ahead_src = nullptr; int ahead_on_device = 0;  // issued into slot (cur + 1) % 3
+    hipEvent_t ev_ready = nullptr;          // side stream: copy + pyramid of the look-ahead slot
+    hipEvent_t ev_detect[2] = {nullptr, nullptr};  // side stream: detect half, per selection work set (frame parity)
+    vo_sel_work selw[2];
     bool have_prev;
     int nL, nC, frame_no;
     char* arena;
@@ -380,15 +387,26 @@ void carve(vo_frame_state* st, char* base, size_t* total) {
     st->pos = b.take<int32_t>(pw); st->plist = b.take<int32_t>(cc); st->counts = b.take<int32_t>(16);
     *total = b.off + 256;
 }
-int copy_image(vo_ctx* ctx, vo_frame_state* st, int slot, const uint8_t* img, int on_device) {
+int copy_image(vo_ctx* ctx, vo_frame_state* st, int slot, const uint8_t* img, int on_device, hipStream_t stream = nullptr) {
     const size_t nb = (size_t)st->nu * st->nv;
-    ST_CHECK(hipMemcpyAsync(st->img[slot], img, nb, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    ST_CHECK(hipMemcpyAsync(st->img[slot], img, nb, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                            stream ? stream : ctx->stream));
     return VO_OK;
 }
-int build_pyramid(vo_ctx* ctx, vo_frame_state* st, int slot) {
+int build_pyramid(vo_ctx* ctx, vo_frame_state* st, int slot, hipStream_t stream = nullptr) {
     int rc = vo_int_frame_prepare(ctx, &st->pyr[slot], st->nu, st->nv, st->o.klt.levels);
     if (rc) return rc;
-    return vo_launch_frame_build(ctx, &st->pyr[slot], st->img[slot]);
+    return vo_launch_frame_build(ctx, &st->pyr[slot], st->img[slot], stream);
+}
+// whatever was issued ahead is abandoned: the ctx stream waits for it (its buffers are about to be reused)
+int drop_lookahead(vo_ctx* ctx, vo_frame_state* st) {
+    if (st->ahead_src) {
+        ST_CHECK(hipStreamWaitEvent(ctx->stream, st->ev_ready, 0));
+        for (int k = 0; k < 2; ++k)
+            if (st->ev_detect[k]) ST_CHECK(hipStreamWaitEvent(ctx->stream, st->ev_detect[k], 0));
+    }
+    st->ahead_src = nullptr; st->next_src = nullptr;
+    return VO_OK;
 }
 int upload_image(vo_ctx* ctx, vo_frame_state* st, int slot, const uint8_t* img, int on_device) {
     int rc = copy_image(ctx, st, slot, img, on_device);
@@ -410,13 +428,17 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     st->capL = o->max_landmarks; st->capC = o->max_candidates; st->PW = st->capL + st->capC;
     st->ring = o->max_temporal_recall + 2; st->P = st->ring + o->max_temporal_recall + 64;
     st->cur = 0; st->have_prev = false; st->nL = st->nC = 0; st->frame_no = 0; st->s = 0;
-    st->arena = nullptr; st->img[0] = st->img[1] = nullptr; st->h_counts = nullptr; st->h_rec = nullptr;
+    st->arena = nullptr; st->img[0] = st->img[1] = st->img[2] = nullptr; st->h_counts = nullptr; st->h_rec = nullptr;
     size_t total = 0;
     carve(st, nullptr, &total);
     hipError_t e = hipMalloc((void**)&st->arena, total);
     if (e == hipSuccess) e = hipMemsetAsync(st->arena, 0, total, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&st->img[0], (size_t)nu * nv);
     if (e == hipSuccess) e = hipMalloc((void**)&st->img[1], (size_t)nu * nv);
+    if (e == hipSuccess) e = hipMalloc((void**)&st->img[2], (size_t)nu * nv);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_counts, 16 * sizeof(int32_t), 0);
     if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_rec, 32 * sizeof(double), 0);
     if (e != hipSuccess) {
@@ -435,11 +457,14 @@ int vo_frame_destroy(vo_ctx* ctx, vo_frame_state* st) {
     if (!ctx || !st) return VO_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side) (void)hipStreamSynchronize(ctx->side);   // a look-ahead may still be running
     if (st->arena) (void)hipFree(st->arena);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         if (st->img[k]) (void)hipFree(st->img[k]);
         if (st->pyr[k].I) (void)hipFree(st->pyr[k].I);
     }
+    if (st->ev_ready) (void)hipEventDestroy(st->ev_ready);
+    for (int k = 0; k < 2; ++k) if (st->ev_detect[k]) (void)hipEventDestroy(st->ev_detect[k]);
     if (st->h_counts) (void)hipHostFree(st->h_counts);
     if (st->h_rec) (void)hipHostFree(st->h_rec);
     delete st;
@@ -453,6 +478,7 @@ int vo_frame_set_state(vo_ctx* ctx, vo_frame_state* st, const double* landmarks,
     if (N > st->capL || C > st->capC) { ctx->last_error = "frame: state larger than max_landmarks / max_candidates"; return VO_ERR_BAD_ARG; }
     if ((N > 0 && (!landmarks || !keypoints || !repro)) || (C > 0 && (!ck || !cfk || !cposes || !ctime))) return VO_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
+    { int rc = drop_lookahead(ctx, st); if (rc) return rc; }   // the frame counter decides the look-ahead's work area
     const int s = st->s, cl = st->capL, cc = st->capC;
     std::vector<double> hL(3 * (size_t)std::max(N, 1)), hk(2 * (size_t)std::max(N, 1)), hc(2 * (size_t)std::max(C, 1)), hf(2 * (size_t)std::max(C, 1));
     for (int i = 0; i < N; ++i) {
@@ -536,9 +562,18 @@ int vo_frame_get_state(vo_ctx* ctx, vo_frame_state* st, double* landmarks, doubl
 int vo_frame_set_image(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device) {
     if (!ctx || !st || !img) return VO_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
-    int rc = upload_image(ctx, st, st->cur, img, on_device);
+    int rc = drop_lookahead(ctx, st);
+    if (rc) return rc;
+    rc = upload_image(ctx, st, st->cur, img, on_device);
     if (rc) return rc;
     st->have_prev = true;
+    return VO_OK;
+}
+
+int vo_frame_announce(vo_ctx* ctx, vo_frame_state* st, const uint8_t* next_img, int on_device) {
+    if (!ctx || !st) return VO_ERR_BAD_ARG;
+    st->next_src = next_img;    // NULL withdraws the announcement
+    st->next_on_device = on_device;
     return VO_OK;
 }
 
@@ -548,7 +583,7 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
     (void)hipSetDevice(ctx->device);
     hipStream_t sm = ctx->stream;
     const vo_frame_opts& o = st->o;
-    const int s = st->s, n = 1 - s, a = st->cur, b = 1 - st->cur;
+    const int s = st->s, n = 1 - s, a = st->cur, b = (st->cur + 1) % 3, c = (st->cur + 2) % 3;
     const int cl = st->capL, cc = st->capC, pw = st->PW;
     const int nL = st->nL, nC = st->nC;
     const int frame_no = st->frame_no + 1;
@@ -556,17 +591,29 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
     double* pose_now = st->poses + 12 * (size_t)slot;
     const double eps = o.klt.eps > 0 ? o.klt.eps : 0.01;
     int rc;
-    if ((rc = copy_image(ctx, st, b, img, on_device))) return rc;
-    // [5a] :330 the image-only half of the selection (corner response, threshold, regional maxima) starts now on
-    // the ctx's side stream, beside the pyramid build / tracking / pose / triangulation; its other half waits
-    // for it at [5b]
-    vo_sel_work selw;
-    if (o.sel.keep > 0) {
-        if ((rc = vo_int_sel_work_prepare(ctx, st->nu, st->nv, o.sel.keep, cl + cc, o.sel.min_distance, &selw))) return rc;
-        if ((rc = vo_int_side_fork(ctx))) return rc;
-        if ((rc = vo_launch_select_detect(ctx, ctx->side, st->img[b], st->nu, st->nv, &o.sel, &selw))) return rc;
+    // [5a] :330 the image-only half of the selection (corner response, threshold, regional maxima) runs on the
+    // ctx's side stream, beside the pyramid build / tracking / pose / triangulation; its other half waits for it
+    // at [5b].  If this image was announced to the previous call (vo_frame_announce), its copy, pyramid and detect
+    // half were issued back then and only have to be waited for.
+    const int set = frame_no & 1;                       // the selection work area of this frame
+    vo_sel_work& selw = st->selw[set];
+    const bool ahead = st->ahead_src && st->ahead_src == img && st->ahead_on_device == on_device;
+    if (ahead) {
+        ST_CHECK(hipStreamWaitEvent(sm, st->ev_ready, 0));
+        st->ahead_src = nullptr;
+    } else {
+        const uint8_t* announced = st->next_src; const int announced_dev = st->next_on_device;
+        if ((rc = drop_lookahead(ctx, st))) return rc;    // something else was issued ahead: it is abandoned
+        st->next_src = announced; st->next_on_device = announced_dev;
+        if ((rc = copy_image(ctx, st, b, img, on_device))) return rc;
+        if (o.sel.keep > 0) {
+            if ((rc = vo_int_sel_work_prepare(ctx, st->nu, st->nv, o.sel.keep, cl + cc, o.sel.min_distance, &selw, set))) return rc;
+            if ((rc = vo_int_side_fork(ctx))) return rc;
+            if ((rc = vo_launch_select_detect(ctx, ctx->side, st->img[b], st->nu, st->nv, &o.sel, &selw))) return rc;
+            ST_CHECK(hipEventRecord(st->ev_detect[set], ctx->side));
+        }
+        if ((rc = build_pyramid(ctx, st, b))) return rc;
     }
-    if ((rc = build_pyramid(ctx, st, b))) return rc;
     hipLaunchKernelGGL(k_frame_reset, dim3(blocks(std::max(pw, 16))), dim3(256), 0, sm, st->counts, st->alive, pw);
 
     // [1] :278-281 and :71 track the landmarks' keypoints and the candidates in one launch; keep the
@@ -577,6 +624,25 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
         hipLaunchKernelGGL(k_concat_points, dim3(blocks(nL + nC)), dim3(256), 0, sm, nL, nC, cl, cc, st->kp[s], st->cu[s], st->pin, pw);
         if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->pin, st->pin + pw, nL + nC, o.klt.block_w, o.klt.block_h,
                                 o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, st->score, nullptr))) return rc;
+    }
+    // look-ahead: the announced image's copy, pyramid and detect half go to the side stream behind the tracking
+    // launch (slot c was last read by the previous call's tracking, the other selection work area by its filter),
+    // i.e. beside this frame's thinly occupied tail
+    if (st->next_src) {
+        vo_sel_work& nw = st->selw[1 - set];
+        if (o.sel.keep > 0 &&
+            (rc = vo_int_sel_work_prepare(ctx, st->nu, st->nv, o.sel.keep, cl + cc, o.sel.min_distance, &nw, 1 - set))) return rc;
+        if ((rc = vo_int_frame_prepare(ctx, &st->pyr[c], st->nu, st->nv, o.klt.levels))) return rc;   // may grow (first use)
+        if ((rc = vo_int_side_fork(ctx))) return rc;
+        if ((rc = copy_image(ctx, st, c, st->next_src, st->next_on_device, ctx->side))) return rc;
+        if ((rc = build_pyramid(ctx, st, c, ctx->side))) return rc;
+        ST_CHECK(hipEventRecord(st->ev_ready, ctx->side));
+        if (o.sel.keep > 0) {
+            if ((rc = vo_launch_select_detect(ctx, ctx->side, st->img[c], st->nu, st->nv, &o.sel, &nw))) return rc;
+            ST_CHECK(hipEventRecord(st->ev_detect[1 - set], ctx->side));
+        }
+        st->ahead_src = st->next_src; st->ahead_on_device = st->next_on_device;
+        st->next_src = nullptr;
     }
     if (nL > 0) {
         TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
@@ -631,7 +697,7 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
     // device (counts[0] + counts[1]), so the host does not wait here
     hipLaunchKernelGGL(k_existing, dim3(blocks(pw)), dim3(256), 0, sm, st->counts, cl, cc, st->kp[n], st->cu[n], st->eu, st->ev);
     if (o.sel.keep > 0) {
-        if ((rc = vo_int_side_join(ctx))) return rc;
+        ST_CHECK(hipStreamWaitEvent(sm, st->ev_detect[set], 0));
         if ((rc = vo_launch_select_filter(ctx, sm, st->nu, st->nv, 0, st->eu, st->ev, cl + cc, st->counts, &o.sel, &selw, st->su, st->sv,
                                           st->slin, nullptr, st->counts + 2))) return rc;
     }

@@ -232,6 +232,8 @@ struct vo_ingest {
     std::condition_variable cv;
     std::mutex hip_mu;   // one thread at a time talks to the copy stream / allocator
     long next_decode = 0, next_out = 0, current = -1;
+    long oldest_held = -1;  // frames oldest_held .. current are in the consumer's hands (vo_ingest_set_hold)
+    int hold = 1;
     bool stop = false;
     std::atomic<long long> decode_ns{0};
 };
@@ -447,7 +449,7 @@ int vo_ingest_open(vo_ctx* ctx, const char* const* paths, int n_paths, const vo_
     }
     if (threads > 64) threads = 64;
     if (depth <= 0) depth = 2 * threads;
-    if (depth < 2) depth = 2;
+    if (depth < 3) depth = 3;   // two frames in the consumer's hands (vo_ingest_set_hold) and one being decoded
     if (depth > 256) depth = 256;
     VO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     vo_ingest* g = new (std::nothrow) vo_ingest();
@@ -495,8 +497,9 @@ int vo_ingest_next(vo_ingest* g, const uint8_t** d_img, int* H, int* W, int* cha
     vo_ctx* ctx = g->ctx;
     const long n = (long)g->paths.size(), depth = (long)g->slots.size();
     if (hipSetDevice(ctx->device) != hipSuccess) return VO_ERR_HIP;
-    if (g->current >= 0) {  // the consumer has moved on from the image handed out last time
-        vo_ingest::Slot* p = &g->slots[g->current % depth];
+    // the consumer has moved on from the oldest image(s) in its hands: at most `hold` stay valid
+    while (g->current >= 0 && g->current - g->oldest_held + 1 >= g->hold) {
+        vo_ingest::Slot* p = &g->slots[g->oldest_held % depth];
         VO_HIP_CHECK(ctx, hipEventRecord(p->released, ctx->stream));
         {
             std::lock_guard<std::mutex> lk(g->mu);
@@ -504,7 +507,7 @@ int vo_ingest_next(vo_ingest* g, const uint8_t** d_img, int* H, int* W, int* cha
             p->state = 0;
         }
         g->cv.notify_all();
-        g->current = -1;
+        if (++g->oldest_held > g->current) { g->current = -1; g->oldest_held = -1; }
     }
     if (g->next_out >= n) return VO_END;
     vo_ingest::Slot* s = &g->slots[g->next_out % depth];
@@ -514,6 +517,7 @@ int vo_ingest_next(vo_ingest* g, const uint8_t** d_img, int* H, int* W, int* cha
         s->state = 3;
     }
     g->current = g->next_out++;
+    if (g->oldest_held < 0) g->oldest_held = g->current;
     if (s->status != VO_OK) {
         ctx->last_error = s->err;
         return s->status;
@@ -524,6 +528,16 @@ int vo_ingest_next(vo_ingest* g, const uint8_t** d_img, int* H, int* W, int* cha
     if (W) *W = s->W;
     if (channels) *channels = s->ch;
     if (index) *index = (int)g->current;
+    return VO_OK;
+}
+
+int vo_ingest_set_hold(vo_ingest* g, int hold) {
+    if (!g) return VO_ERR_BAD_ARG;
+    if (g->next_out != 0 || hold < 1 || hold > (int)g->slots.size() - 1) {
+        g->ctx->last_error = "vo_ingest_set_hold: before the first vo_ingest_next, 1 <= hold <= depth - 1";
+        return VO_ERR_BAD_ARG;
+    }
+    g->hold = hold;
     return VO_OK;
 }
 

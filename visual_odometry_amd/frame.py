@@ -79,9 +79,15 @@ class FrameLoop:
                                candidate_first_keypoints=cf, candidate_first_poses=cp,
                                candidate_time_indxs=ct.astype(np.int64))
 
-    def processFrame(self, curr_img):
-        """-> (curr_pose 4x3 [R_WC; t_WC], pose_status, info dict); the new state stays on the device."""
+    def processFrame(self, curr_img, next_img=None):
+        """-> (curr_pose 4x3 [R_WC; t_WC], pose_status, info dict); the new state stays on the device.
+        next_img: the image the following call will process, if it is at hand already (vo_frame_announce): its
+        pyramid and corner detection then run beside this frame's tail.  It must be the very object (same memory)
+        that the following call passes, kept unchanged until then.  Same results either way."""
         keep, p, dev = self._img(curr_img)
+        if next_img is not None:
+            self._next_keep, pn, devn = self._img(next_img)       # kept alive until the next call
+            self.ctx.call("vo_frame_announce", self.h, pn, devn)
         pose = np.zeros((4, 3)); info = FrameInfo()
         self.ctx.call("vo_frame_process", self.h, p, dev, ptr(pose), C.byref(info))
         return pose, info.status, {n: getattr(info, n) for n, _ in FrameInfo._fields_}

@@ -106,7 +106,9 @@ class DeviceImage:
 class FrameStream:
     """Decode pool over a list of files -> device images in order (vo_ingest_*)."""
 
-    def __init__(self, paths, threads=0, depth=0, keep_rgb=False, ctx=None):
+    def __init__(self, paths, threads=0, depth=0, keep_rgb=False, ctx=None, hold=1):
+        """hold: how many of the frames handed out stay valid (2: the current one and the one after it, which is
+        what FrameLoop.processFrame(curr, next_img) needs)."""
         self.ctx = ctx or _lib.Context.default()
         self.paths = [os.fspath(p) for p in paths]
         arr = (C.c_char_p * len(self.paths))(*[p.encode() for p in self.paths])
@@ -114,6 +116,8 @@ class FrameStream:
         opts = IngestOpts(int(threads), int(depth), int(bool(keep_rgb)))
         self.ctx.call("vo_ingest_open", arr, len(self.paths), C.byref(opts), C.byref(self.h))
         self.lib = self.ctx.lib
+        if int(hold) != 1:
+            self.ctx.check(self.lib.vo_ingest_set_hold(self.h, int(hold)), "vo_ingest_set_hold")
         self.lib.vo_ingest_next.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                             C.POINTER(C.c_int), C.POINTER(C.c_int)]
         self.current = None

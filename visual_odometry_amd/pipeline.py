@@ -44,14 +44,17 @@ def run_sequence(loader, num_frames=300, bootstrap_frames=(20, 21), MaxNumLandma
     loader.reset(first)                                                                          # :43
     last = min(first + int(num_frames), loader.last_frame + 1)
     traj = Trajectory()                                                                          # :72-74
-    fs = loader.stream(first, last, threads=threads, depth=depth)
+    fs = loader.stream(first, last, threads=threads, depth=depth, hold=2)
     n_landmarks = []
     t0 = time.perf_counter()
     try:
-        for img in fs:
-            p, status, info = loop.processFrame(img)                                             # :94-95
+        img = next(fs, None)
+        while img is not None:
+            nxt = next(fs, None)        # the pool runs ahead: the frame after this one is announced to the loop
+            p, status, info = loop.processFrame(img, nxt)                                        # :94-95
             traj.append(p, status)                                                               # :101
             n_landmarks.append(info["n_landmarks"])
+            img = nxt
     finally:
         dt = time.perf_counter() - t0
         fs.close()
