@@ -2,7 +2,10 @@
 //   h = vo_frame_mex('create', opts, [H W], K)          opts: the properties of :22-37 (+ Seed), K = IntrinsicMatrix
 //   vo_frame_mex('set_state', h, state, prev_img)       state: the struct of :308-315 / :338-345 (poses as a cell)
 //   [pose, status, counts] = vo_frame_mex('process', h, img)         img: H x W uint8, or a uint64 device handle
-//   state = vo_frame_mex('get_state', h)                              (from vo_ingest_mex('next', ...))
+//   [pose, status, counts] = vo_frame_mex('process', h, dimg, dnext) (from vo_ingest_mex('next', ...)); dnext: the
+//                                                                     handle of the frame after it (pool opened with
+//                                                                     hold = 2), announced with vo_frame_announce
+//   state = vo_frame_mex('get_state', h)
 //   vo_frame_mex('destroy', h)
 // The loop works zero-based and row-major: points lose 1, the principal point loses 1, images and poses are
 // transposed here (a MATLAB H x W array is W columns of H bytes).
@@ -96,6 +99,8 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         double pose[12];
         vo_frame_info info;
         if (mxIsUint64(prhs[2])) {   // a device image of the decode pool: row-major already
+            if (nrhs > 3 && mxIsUint64(prhs[3]) && *(uint64_t*)mxGetData(prhs[3]))   // look-ahead: the frame after this one
+                vo_mex_check(vo_frame_announce(ctx, st, (const uint8_t*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[3])), 1), "vo_frame_announce");
             vo_mex_check(vo_frame_process(ctx, st, (const uint8_t*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[2])), 1, pose, &info), "vo_frame_process");
         } else {
             std::vector<uint8_t> img;

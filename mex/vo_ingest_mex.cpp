@@ -1,8 +1,10 @@
 // The decode pool (vo_ingest_*) for MATLAB: imread / rgb2gray of a whole sequence off the interpreter's thread
 // (main.m:15-30,52-59; utils/dataLoaderKitti.m:29).
-//   ing = vo_ingest_mex('open', files, opts)      files: cell array of char; opts: threads, depth, keep_rgb
+//   ing = vo_ingest_mex('open', files, opts)      files: cell array of char; opts: threads, depth, keep_rgb, hold
+//                                                 (hold = 2: the frame before the current one stays valid too)
 //   [ok, dimg, H, W] = vo_ingest_mex('next', ing) dimg: uint64 device handle of an H-rows-of-W-bytes gray image,
-//                                                 valid until the next call; ok = false after the last file
+//                                                 valid until the next call (the one after it with hold = 2);
+//                                                 ok = false after the last file
 //   img = vo_ingest_mex('read', ing)              the current frame as a MATLAB H x W uint8 array (tests, plots)
 //   vo_ingest_mex('close', ing)
 #include <string.h>
@@ -34,6 +36,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         if (nrhs > 2) { o.threads = (int)vo_opt(prhs[2], "threads", 0); o.depth = (int)vo_opt(prhs[2], "depth", 0); o.keep_rgb = (int)vo_opt(prhs[2], "keep_rgb", 0); }
         vo_ingest* g = nullptr;
         vo_mex_check(vo_ingest_open(ctx, ptrs.data(), n, &o, &g), "vo_ingest_open");
+        const int hold = nrhs > 2 ? (int)vo_opt(prhs[2], "hold", 1) : 1;
+        if (hold != 1) {
+            const int rc = vo_ingest_set_hold(g, hold);
+            if (rc != VO_OK) { (void)vo_ingest_close(g); vo_mex_check(rc, "vo_ingest_set_hold"); }
+        }
         plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
         *(uint64_t*)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)g;
     } else if (!strcmp(cmd, "next")) {

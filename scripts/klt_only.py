@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 mi = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 ctx = _lib.Context(0)
-wl = FrameWorkload(ctx, n, 16, n_frames=2, num_hyp=8, max_iters=mi)
+wl = FrameWorkload(ctx, n, 16, n_frames=2, num_hyp=8, max_iters=mi, ahead=False)
 wl.build(1, 1)
 wl.track_landmarks(0, 1); wl.sync()
 ctx.counters(reset=True)

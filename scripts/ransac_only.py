@@ -4,7 +4,7 @@ from visual_odometry_amd import _lib
 from visual_odometry_amd.device import FrameWorkload
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 25000
 ctx = _lib.Context(0)
-wl = FrameWorkload(ctx, n, 16, n_frames=2, num_hyp=2000)
+wl = FrameWorkload(ctx, n, 16, n_frames=2, num_hyp=2000, ahead=False)
 wl.pose(); wl.sync()
 ctx.counters(reset=True)
 ctx.timer_start()
