@@ -319,6 +319,17 @@ __device__ __forceinline__ int cell_exact(float c, int cells, int n, float inv_n
     return b;
 }
 
+// The same cell through an fp32 estimate when that cannot be wrong: the estimate (c * cells) * (1/n) is within
+// 3 * 2^-24 relative of the quotient, i.e. within 4e-4 of it for up to 2048 cells, so a fractional part inside
+// [1e-3, 0.999] leaves the floor certain; only estimates next to a cell border pay for the exact form.
+__device__ __forceinline__ int cell_of(float c, int cells, int n, float inv_n) {
+    const float e = (c * (float)cells) * inv_n;
+    const float f = floorf(e);
+    const float r = e - f;
+    if (cells <= 2048 && r > 1e-3f && r < 0.999f) return (int)f;
+    return cell_exact(c, cells, n, inv_n);
+}
+
 __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
     __shared__ int s_cnt[16];
     __shared__ int s_remaining, s_selected, s_round_sel, s_nlist;
@@ -370,11 +381,14 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
 #pragma unroll
             for (int k = 0; k < UNI_KPT; ++k) { // phase 1: per-cell maximum metric
                 if (fp[k] == NONE || (fp[k] >> 31)) continue;
-                const int bu = clampi(cell_exact(fu[k], cells_u, a.nu, inv_nu), 0, cells_u - 1);
-                const int bv = clampi(cell_exact(fv[k], cells_v, a.nv, inv_nv), 0, cells_v - 1);
+                const int bu = clampi(cell_of(fu[k], cells_u, a.nu, inv_nu), 0, cells_u - 1);
+                const int bv = clampi(cell_of(fv[k], cells_v, a.nv, inv_nv), 0, cells_v - 1);
                 const unsigned cell = (unsigned)(bv * cells_u + bu);
                 fp[k] = (fp[k] & IDX) | (cell << 17);
-                atomicMax(&s_key[cell], fk[k]);
+                // a plain look first: the table only grows, so a key that does not beat the value seen cannot win,
+                // and after the first few updates almost none does -- thousands of corners on a handful of cells
+                // (late rounds) would otherwise serialise on the same LDS words
+                if (fk[k] > *(volatile unsigned long long*)&s_key[cell]) atomicMax(&s_key[cell], fk[k]);
             }
             __syncthreads();
 #pragma unroll
@@ -439,13 +453,13 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
         for (int e = t; e < nl; e += 1024) {
             const int i = a.klist[e];
             if (a.sel[i]) { a.kcell[e] = -1; continue; }
-            const int bu = clampi(cell_exact(a.cu[i], cells_u, a.nu, inv_nu), 0, cells_u - 1);
-            const int bv = clampi(cell_exact(a.cv[i], cells_v, a.nv, inv_nv), 0, cells_v - 1);
+            const int bu = clampi(cell_of(a.cu[i], cells_u, a.nu, inv_nu), 0, cells_u - 1);
+            const int bv = clampi(cell_of(a.cv[i], cells_v, a.nv, inv_nv), 0, cells_v - 1);
             const int cell = bv * cells_u + bu;
             a.kcell[e] = cell;
             const unsigned long long key = (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull;
-            if (lds) atomicMax(&s_key[cell], key);
-            else atomicMax(&a.cell_key[cell], key);
+            if (lds) { if (key > *(volatile unsigned long long*)&s_key[cell]) atomicMax(&s_key[cell], key); }
+            else if (key > __hip_atomic_load(&a.cell_key[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.cell_key[cell], key);
         }
         __threadfence_block();
         __syncthreads();
