@@ -306,8 +306,11 @@ __global__ void k_existing(const int32_t* counts, int capL, int capC, const doub
 }
 
 // :338-345 append the new candidates: first keypoint = keypoint, first pose = this frame's, time -1
+// ... and, last kernel of a frame, gather what the host reads back into one record (one copy instead of three):
+// the pose step's record (16 doubles), the pose (12), the counters (16 int32)
 __global__ void k_append_new(int32_t* counts, int capC, const float* su, const float* sv, int pose_slot, double* cu,
-                             double* cf, int32_t* cpose, int32_t* ctime) {
+                             double* cf, int32_t* cpose, int32_t* ctime, const double* rsout, const double* pose_now,
+                             double* packed) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int nC = counts[1];
     int m = counts[2];
@@ -319,7 +322,13 @@ __global__ void k_append_new(int32_t* counts, int capC, const float* su, const f
         cu[d] = u; cu[capC + d] = v; cf[d] = u; cf[capC + d] = v;
         cpose[d] = pose_slot; ctime[d] = -1;
     }
-    if (i == 0) { counts[3] = nC + take; counts[4] = m > room ? 1 : 0; counts[5] = take; }
+    if (i == 0) {
+        counts[3] = nC + take; counts[4] = m > room ? 1 : 0; counts[5] = take;
+        for (int k = 0; k < 16; ++k) packed[k] = rsout[k];
+        for (int k = 0; k < 12; ++k) packed[16 + k] = pose_now[k];
+        int32_t* pc = (int32_t*)(packed + 28);
+        for (int k = 0; k < 16; ++k) pc[k] = k == 3 ? nC + take : (k == 4 ? (m > room ? 1 : 0) : (k == 5 ? take : counts[k]));
+    }
 }
 
 } // namespace
@@ -345,7 +354,7 @@ struct vo_frame_state {
     double *L[2], *kp[2], *rep[2], *cu[2], *cf[2];
     int32_t *cpose[2], *ctime[2];
     int s;                                  // index of the current state
-    double *poses, *K, *rsout;
+    double *poses, *K, *rsout, *packed;   // packed: what a frame's host read-back takes (k_append_new)
     // work
     double *pin, *q, *vk, *vl, *err, *cq, *X, *crep, *cang, *wkp, *wL, *wrep;
     float *score, *eu, *ev, *su, *sv;
@@ -376,6 +385,7 @@ void carve(vo_frame_state* st, char* base, size_t* total) {
         st->cpose[k] = b.take<int32_t>(cc); st->ctime[k] = b.take<int32_t>(cc);
     }
     st->poses = b.take<double>(12 * (size_t)st->P); st->K = b.take<double>(9); st->rsout = b.take<double>(16);
+    st->packed = b.take<double>(40);
     st->pin = b.take<double>(2 * pw); st->q = b.take<double>(2 * pw); st->vk = b.take<double>(2 * cl); st->vl = b.take<double>(3 * cl); st->err = b.take<double>(cl);
     st->cq = b.take<double>(2 * cc); st->X = b.take<double>(3 * cc); st->crep = b.take<double>(cc); st->cang = b.take<double>(cc);
     st->wkp = b.take<double>(2 * pw); st->wL = b.take<double>(3 * pw); st->wrep = b.take<double>(pw);
@@ -440,7 +450,7 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_counts, 16 * sizeof(int32_t), 0);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_rec, 32 * sizeof(double), 0);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_rec, 40 * sizeof(double), 0);
     if (e != hipSuccess) {
         ctx->last_error = std::string("frame: allocation failed: ") + hipGetErrorString(e);
         vo_frame_destroy(ctx, st);
@@ -702,12 +712,11 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
                                           st->slin, nullptr, st->counts + 2))) return rc;
     }
     hipLaunchKernelGGL(k_append_new, dim3(blocks(std::max(o.sel.keep, 1))), dim3(256), 0, sm, st->counts, cc, st->su, st->sv, slot,
-                       st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]);
+                       st->cu[n], st->cf[n], st->cpose[n], st->ctime[n], st->rsout, pose_now, st->packed);
     ST_CHECK(hipGetLastError());
-    ST_CHECK(hipMemcpyAsync(st->h_counts, st->counts, 16 * 4, hipMemcpyDeviceToHost, sm));
-    ST_CHECK(hipMemcpyAsync(st->h_rec, st->rsout, 128, hipMemcpyDeviceToHost, sm));
-    ST_CHECK(hipMemcpyAsync(st->h_rec + 16, pose_now, 96, hipMemcpyDeviceToHost, sm));
+    ST_CHECK(hipMemcpyAsync(st->h_rec, st->packed, 36 * sizeof(double), hipMemcpyDeviceToHost, sm));
     ST_CHECK(hipStreamSynchronize(sm));
+    memcpy(st->h_counts, st->h_rec + 28, 16 * sizeof(int32_t));
     int32_t ri[5];
     memcpy(ri, st->h_rec + 12, sizeof ri);
     memcpy(pose43, st->h_rec + 16, 96);
