@@ -380,12 +380,17 @@ int vo_klt_track(vo_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int H, i
 
 #include "vo_api_rest.inc"
 
-int vo_int_side_fork(vo_ctx* ctx) {
+int vo_int_side_ensure(vo_ctx* ctx) {
     if (!ctx->side) {
         VO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
         VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     }
+    return VO_OK;
+}
+int vo_int_side_fork(vo_ctx* ctx) {
+    int rc = vo_int_side_ensure(ctx);
+    if (rc) return rc;
     VO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     VO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
     return VO_OK;

@@ -92,6 +92,7 @@ int vo_launch_select_filter(vo_ctx* ctx, hipStream_t stream, int nu, int nv, int
                             int32_t* d_out_count);
 // side stream: fork = the side stream waits for everything enqueued on the ctx stream so far; join = the ctx
 // stream waits for everything enqueued on the side stream so far
+int vo_int_side_ensure(vo_ctx* ctx);   // the side stream exists
 int vo_int_side_fork(vo_ctx* ctx);
 int vo_int_side_join(vo_ctx* ctx);
 int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is_rows, const float* d_eu,

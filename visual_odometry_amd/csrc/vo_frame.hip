@@ -345,6 +345,7 @@ struct vo_frame_state {
     const uint8_t* next_src = nullptr; int next_on_device = 0;    // announced, not issued yet
     const uint8_t* ahead_src = nullptr; int ahead_on_device = 0;  // issued into slot (cur + 1) % 3
     hipEvent_t ev_ready = nullptr;          // side stream: copy + pyramid of the look-ahead slot
+    hipEvent_t ev_fork_la = nullptr;        // ctx stream: behind the tracking launch
     hipEvent_t ev_detect[2] = {nullptr, nullptr};  // side stream: detect half, per selection work set (frame parity)
     vo_sel_work selw[2];
     bool have_prev;
@@ -447,6 +448,7 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     if (e == hipSuccess) e = hipMalloc((void**)&st->img[1], (size_t)nu * nv);
     if (e == hipSuccess) e = hipMalloc((void**)&st->img[2], (size_t)nu * nv);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_fork_la, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_counts, 16 * sizeof(int32_t), 0);
@@ -474,6 +476,7 @@ int vo_frame_destroy(vo_ctx* ctx, vo_frame_state* st) {
         if (st->pyr[k].I) (void)hipFree(st->pyr[k].I);
     }
     if (st->ev_ready) (void)hipEventDestroy(st->ev_ready);
+    if (st->ev_fork_la) (void)hipEventDestroy(st->ev_fork_la);
     for (int k = 0; k < 2; ++k) if (st->ev_detect[k]) (void)hipEventDestroy(st->ev_detect[k]);
     if (st->h_counts) (void)hipHostFree(st->h_counts);
     if (st->h_rec) (void)hipHostFree(st->h_rec);
@@ -635,25 +638,9 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
         if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->pin, st->pin + pw, nL + nC, o.klt.block_w, o.klt.block_h,
                                 o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, st->score, nullptr))) return rc;
     }
-    // look-ahead: the announced image's copy, pyramid and detect half go to the side stream behind the tracking
-    // launch (slot c was last read by the previous call's tracking, the other selection work area by its filter),
-    // i.e. beside this frame's thinly occupied tail
-    if (st->next_src) {
-        vo_sel_work& nw = st->selw[1 - set];
-        if (o.sel.keep > 0 &&
-            (rc = vo_int_sel_work_prepare(ctx, st->nu, st->nv, o.sel.keep, cl + cc, o.sel.min_distance, &nw, 1 - set))) return rc;
-        if ((rc = vo_int_frame_prepare(ctx, &st->pyr[c], st->nu, st->nv, o.klt.levels))) return rc;   // may grow (first use)
-        if ((rc = vo_int_side_fork(ctx))) return rc;
-        if ((rc = copy_image(ctx, st, c, st->next_src, st->next_on_device, ctx->side))) return rc;
-        if ((rc = build_pyramid(ctx, st, c, ctx->side))) return rc;
-        ST_CHECK(hipEventRecord(st->ev_ready, ctx->side));
-        if (o.sel.keep > 0) {
-            if ((rc = vo_launch_select_detect(ctx, ctx->side, st->img[c], st->nu, st->nv, &o.sel, &nw))) return rc;
-            ST_CHECK(hipEventRecord(st->ev_detect[1 - set], ctx->side));
-        }
-        st->ahead_src = st->next_src; st->ahead_on_device = st->next_on_device;
-        st->next_src = nullptr;
-    }
+    // look-ahead, part 1: the point of the ctx stream behind which the side stream may start (the tracking launch
+    // is the last reader of the slot and of the work area that the look-ahead overwrites)
+    if (st->next_src) ST_CHECK(hipEventRecord(st->ev_fork_la, sm));
     if (nL > 0) {
         TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
         hipLaunchKernelGGL(k_compact<TrackedOp>, dim3(1), dim3(1024), 0, sm, top, nL, st->counts + 6, nullptr);
@@ -713,6 +700,27 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
     }
     hipLaunchKernelGGL(k_append_new, dim3(blocks(std::max(o.sel.keep, 1))), dim3(256), 0, sm, st->counts, cc, st->su, st->sv, slot,
                        st->cu[n], st->cf[n], st->cpose[n], st->ctime[n], st->rsout, pose_now, st->packed);
+    // look-ahead, part 2: the announced image's copy, pyramid and detect half on the side stream.  Enqueued here,
+    // after this frame's own launches (the host's launch rate is what the loop runs at: the ctx stream must not
+    // wait for launches of work it does not need), it may run since the tracking launch finished -- beside
+    // whatever of this frame's tail is still queued.
+    if (st->next_src) {
+        vo_sel_work& nw = st->selw[1 - set];
+        if (o.sel.keep > 0 &&
+            (rc = vo_int_sel_work_prepare(ctx, st->nu, st->nv, o.sel.keep, cl + cc, o.sel.min_distance, &nw, 1 - set))) return rc;
+        if ((rc = vo_int_frame_prepare(ctx, &st->pyr[c], st->nu, st->nv, o.klt.levels))) return rc;   // may grow (first use)
+        if ((rc = vo_int_side_ensure(ctx))) return rc;
+        ST_CHECK(hipStreamWaitEvent(ctx->side, st->ev_fork_la, 0));   // long satisfied by the time this is enqueued
+        if ((rc = copy_image(ctx, st, c, st->next_src, st->next_on_device, ctx->side))) return rc;
+        if ((rc = build_pyramid(ctx, st, c, ctx->side))) return rc;
+        ST_CHECK(hipEventRecord(st->ev_ready, ctx->side));
+        if (o.sel.keep > 0) {
+            if ((rc = vo_launch_select_detect(ctx, ctx->side, st->img[c], st->nu, st->nv, &o.sel, &nw))) return rc;
+            ST_CHECK(hipEventRecord(st->ev_detect[1 - set], ctx->side));
+        }
+        st->ahead_src = st->next_src; st->ahead_on_device = st->next_on_device;
+        st->next_src = nullptr;
+    }
     ST_CHECK(hipGetLastError());
     ST_CHECK(hipMemcpyAsync(st->h_rec, st->packed, 36 * sizeof(double), hipMemcpyDeviceToHost, sm));
     ST_CHECK(hipStreamSynchronize(sm));
