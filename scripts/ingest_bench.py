@@ -92,14 +92,17 @@ for t in threads:
     st.keypoints, st.landmarks, st.reproError = kp.astype(np.float64), lift(kp[:, 0], kp[:, 1]), np.zeros(len(kp))
     st.candidate_first_poses = np.zeros((0, 4, 3))
     loop.set_state(st, frames[0])
-    fs = ingest.FrameStream(paths[1:], threads=t)
+    fs = ingest.FrameStream(paths[1:], threads=t, hold=2)      # two frames in hand: the current one and the one announced
     t0 = time.perf_counter()
     n = 0
     ok = 0
-    for img in fs:
-        pose, status, info = loop.processFrame(img)
+    img = next(fs, None)
+    while img is not None:
+        nxt = next(fs, None)
+        pose, status, info = loop.processFrame(img, nxt)
         ok += status == 0
         n += 1
+        img = nxt
     dt = time.perf_counter() - t0
     print(f"pool + processFrame threads {t:2d}: {n / dt:7.0f} frames/s ({ok}/{n} poses ok, {info['n_landmarks']} landmarks at the end)")
     fs.close(); loop.close()
