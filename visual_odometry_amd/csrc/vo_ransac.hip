@@ -383,10 +383,17 @@ __device__ __forceinline__ bool improves(int mode, int min_inl, int c, unsigned 
 }
 __device__ __forceinline__ void hyp_best(const int32_t* cnt, const unsigned long long* cost, int mode, int h, int& s_best,
                                          int& c, unsigned long long& q) {
-    s_best = 0;
+    // the four solutions' records in two vector loads each, compared in registers (a compare that re-reads
+    // cnt[4h + s_best] chains up to three dependent global loads per hypothesis)
+    const int4 c4 = *reinterpret_cast<const int4*>(cnt + 4 * (long)h);
+    const ulonglong2 qa = *reinterpret_cast<const ulonglong2*>(cost + 4 * (long)h);
+    const ulonglong2 qb = *reinterpret_cast<const ulonglong2*>(cost + 4 * (long)h + 2);
+    const int cs[4] = {c4.x, c4.y, c4.z, c4.w};
+    const unsigned long long qs[4] = {qa.x, qa.y, qb.x, qb.y};
+    s_best = 0; c = cs[0]; q = qs[0];
+#pragma unroll
     for (int s = 1; s < 4; ++s)
-        if (mode == 0 ? (cnt[4 * h + s] > cnt[4 * h + s_best]) : (cost[4 * h + s] < cost[4 * h + s_best])) s_best = s;
-    c = cnt[4 * h + s_best]; q = cost[4 * h + s_best];
+        if (mode == 0 ? (cs[s] > c) : (qs[s] < q)) { s_best = s; c = cs[s]; q = qs[s]; }
 }
 __device__ __forceinline__ double ransac_limit(double confidence, int bcnt, int m, int sample_size) {
     double orat = 1.0 - (double)bcnt / (double)m;

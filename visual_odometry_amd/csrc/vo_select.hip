@@ -199,15 +199,23 @@ __global__ __launch_bounds__(DT_BLOCK) void k_detect(const double* __restrict__ 
 }
 
 // exclusive scan of the per-block counts (single block), total -> *m0 (clamped to cap)
+constexpr int SCAN_LDS = 8192;   // entries staged through LDS (coalesced global reads and writes)
 __global__ __launch_bounds__(1024) void k_scan_counts(const int32_t* __restrict__ counts, int nblk, int32_t* offs,
                                                        int32_t* m0, int cap) {
     // exclusive prefix sums of `counts` (each thread owns `per` consecutive entries): wave scan by shuffles, the
-    // 16 wave totals through LDS
+    // 16 wave totals through LDS.  Up to SCAN_LDS entries the table goes through LDS, so that global memory sees
+    // coalesced rows instead of 2 x per strided accesses per thread (latency, not bytes, is what this kernel costs).
     __shared__ int s_wave[16];
+    __shared__ int s_tab[SCAN_LDS];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int per = (nblk + 1023) / 1024;
+    const bool staged = nblk <= SCAN_LDS;
+    if (staged) {
+        for (int i = t; i < nblk; i += 1024) s_tab[i] = counts[i];
+        __syncthreads();
+    }
     int s = 0;
-    for (int k = 0; k < per; ++k) { int i = t * per + k; if (i < nblk) s += counts[i]; }
+    for (int k = 0; k < per; ++k) { int i = t * per + k; if (i < nblk) s += staged ? s_tab[i] : counts[i]; }
     int inc = s;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
@@ -217,7 +225,13 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int32_t* __restrict_
 #pragma unroll
     for (int w = 0; w < 16; ++w) { const int c = s_wave[w]; if (w < wid) before += c; total += c; }
     int run = before + inc - s;
-    for (int k = 0; k < per; ++k) { int i = t * per + k; if (i < nblk) { offs[i] = run; run += counts[i]; } }
+    if (staged) {
+        for (int k = 0; k < per; ++k) { int i = t * per + k; if (i < nblk) { const int c = s_tab[i]; s_tab[i] = run; run += c; } }
+        __syncthreads();
+        for (int i = t; i < nblk; i += 1024) offs[i] = s_tab[i];
+    } else {
+        for (int k = 0; k < per; ++k) { int i = t * per + k; if (i < nblk) { offs[i] = run; run += counts[i]; } }
+    }
     if (t == 0) *m0 = total < cap ? total : cap;
 }
 
