@@ -427,7 +427,7 @@ __device__ __forceinline__ BState shfl_up_state(const BState& x, int d) {
 // One block of BEST_NT threads, each owning a contiguous chunk of hypotheses: local pass, two-level
 // scan of the best-so-far records (wave shuffles, then the 16 wave totals through LDS), then a
 // re-walk of the chunk with the carried-in record that looks for the adaptive stop.
-constexpr int BEST_NT = 1024;
+constexpr int BEST_NT = 256;   // 1024 and 64 were measured too: 8 and 6 us slower per 2000-hypothesis launch
 constexpr int RANSAC_STAGE = 256;  // hypotheses of the first stage of an adaptive run (a multiple of 64 and of SC_HB)
 __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
     __shared__ BState s_wave[BEST_NT / 64];
