@@ -319,7 +319,10 @@ struct UniArgs {
 };
 
 constexpr int UNI_LDS_CELLS = 2048; // per-round cell tables live in LDS up to this many cells
-constexpr int UNI_KPT = 16;          // kept corners a thread can hold in registers across the rounds
+#ifndef UNI_NT
+#define UNI_NT 1024   // 512 / 256 threads with 32 / 64 corners each were measured: 22 / 80 us slower in the frame loop
+#endif
+constexpr int UNI_KPT = 16 * 1024 / UNI_NT;   // kept corners a thread can hold in registers across the rounds
 
 // floor((double)c * cells / n) without a division: the product is exact in double (24 + 13 bits),
 // a float estimate is corrected by exact integer-valued comparisons.  Identical to the oracle's
@@ -344,8 +347,8 @@ __device__ __forceinline__ int cell_of(float c, int cells, int n, float inv_n) {
     return cell_exact(c, cells, n, inv_n);
 }
 
-__global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
-    __shared__ int s_cnt[16];
+__global__ __launch_bounds__(UNI_NT) void k_uniform(UniArgs a) {
+    __shared__ int s_cnt[UNI_NT / 64];
     __shared__ int s_remaining, s_selected, s_round_sel, s_nlist;
     __shared__ unsigned long long s_key[UNI_LDS_CELLS];
     __shared__ int s_idx[UNI_LDS_CELLS];
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
     // asking for at least as many points as survive selects them all (bootstrap: selectUniform over every
     // detected corner, modules/bootstrap.m:36-38) -- the rounds would end there too
     const bool all = a.n_keep >= nl;
-    const bool fast = !all && nl <= 1024 * UNI_KPT && a.n_keep <= UNI_LDS_CELLS - 1 && m <= 0x1ffff;
+    const bool fast = !all && nl <= UNI_NT * UNI_KPT && a.n_keep <= UNI_LDS_CELLS - 1 && m <= 0x1ffff;
     if (fast) {
         // per corner: coordinates, metric key, and one packed word: index (bits 0-16, corners < 2^17 by
         // the capacity rule n/4+16 is checked on the host), this round's cell (17-27), selected (31)
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
         constexpr unsigned NONE = 0xffffffffu, IDX = 0x1ffffu, CELL_NONE = 0x7ffu;
 #pragma unroll
         for (int k = 0; k < UNI_KPT; ++k) {
-            const int e = t + 1024 * k;
+            const int e = t + UNI_NT * k;
             fp[k] = NONE; fu[k] = fv[k] = 0.0f; fk[k] = 0ull;
             if (e < nl) {
                 const int i = a.klist[e];
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
             long w = (h * W) / H; if (w < 1) w = 1; if (h * w > want) w = want / h;
             const int cells_u = (int)(a.u_is_rows ? h : w), cells_v = (int)(a.u_is_rows ? w : h);
             const int nc = cells_u * cells_v;
-            for (int k = t; k < nc; k += 1024) { s_key[k] = 0ull; s_idx[k] = 0x7fffffff; }
+            for (int k = t; k < nc; k += UNI_NT) { s_key[k] = 0ull; s_idx[k] = 0x7fffffff; }
             if (t == 0) s_round_sel = 0;
             __syncthreads();
 #pragma unroll
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
             if (fp[k] != NONE && (fp[k] >> 31)) s_idx[atomicAdd(&s_nlist, 1)] = (int)(fp[k] & IDX);
         __syncthreads();
         const int S = s_nlist;
-        for (int e = t; e < S; e += 1024) {
+        for (int e = t; e < S; e += UNI_NT) {
             const int i = s_idx[e];
             int pos = 0;
             for (int j = 0; j < S; ++j) pos += s_idx[j] < i ? 1 : 0;
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
         if (t == 0) *a.out_count = S;
         return;
     }
-    for (int i = t; i < m; i += 1024) a.sel[i] = all ? a.keep[i] : 0;
+    for (int i = t; i < m; i += UNI_NT) a.sel[i] = all ? a.keep[i] : 0;
     __threadfence_block();
     __syncthreads();
     while (!all) {
@@ -457,14 +460,14 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
         const int cells_u = (int)(a.u_is_rows ? h : w), cells_v = (int)(a.u_is_rows ? w : h);
         const int nc = cells_u * cells_v;
         const bool lds = nc <= UNI_LDS_CELLS; // wave-uniform: LDS atomics when the table fits, else L2 atomics
-        for (int k = t; k < nc; k += 1024) {
+        for (int k = t; k < nc; k += UNI_NT) {
             if (lds) { s_key[k] = 0ull; s_idx[k] = 0x7fffffff; }
             else { a.cell_key[k] = 0ull; a.cell_idx[k] = 0x7fffffff; }
         }
         if (t == 0) s_round_sel = 0;
         __syncthreads();
         // phase 1: per-cell maximum metric (+1 so that a zero metric still differs from "empty")
-        for (int e = t; e < nl; e += 1024) {
+        for (int e = t; e < nl; e += UNI_NT) {
             const int i = a.klist[e];
             if (a.sel[i]) { a.kcell[e] = -1; continue; }
             const int bu = clampi(cell_of(a.cu[i], cells_u, a.nu, inv_nu), 0, cells_u - 1);
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
         __threadfence_block();
         __syncthreads();
         // phase 2: lowest index among the maxima
-        for (int e = t; e < nl; e += 1024) {
+        for (int e = t; e < nl; e += UNI_NT) {
             const int cell = a.kcell[e];
             if (cell < 0) continue;
             const int i = a.klist[e];
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
         __threadfence_block();
         __syncthreads();
         int got = 0;
-        for (int k = t; k < nc; k += 1024) {
+        for (int k = t; k < nc; k += UNI_NT) {
             const int idx = lds ? s_idx[k] : __hip_atomic_load(&a.cell_idx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (idx != 0x7fffffff) { a.sel[idx] = 1; ++got; }
         }
@@ -503,14 +506,14 @@ __global__ __launch_bounds__(1024) void k_uniform(UniArgs a) {
     // ordered compaction of sel[] (ascending corner index)
     int base = 0;
     const int lane = t & 63, wid = t >> 6;
-    for (int start = 0; start < m; start += 1024) {
+    for (int start = 0; start < m; start += UNI_NT) {
         const int i = start + t;
         const bool s = i < m && a.sel[i];
         const unsigned long long bal = __ballot(s);
         if (lane == 0) s_cnt[wid] = __popcll(bal);
         __syncthreads();
         int pos = base, tot = 0;
-        for (int w2 = 0; w2 < 16; ++w2) { if (w2 < wid) pos += s_cnt[w2]; tot += s_cnt[w2]; }
+        for (int w2 = 0; w2 < UNI_NT / 64; ++w2) { if (w2 < wid) pos += s_cnt[w2]; tot += s_cnt[w2]; }
         pos += __popcll(bal & ((1ull << lane) - 1ull));
         if (s) {
             a.out_u[pos] = a.cu[i]; a.out_v[pos] = a.cv[i];
@@ -694,7 +697,7 @@ int vo_launch_select_filter(vo_ctx* ctx, hipStream_t stream, int nu, int nv, int
     a.n_keep = o->keep; a.nu = nu; a.nv = nv; a.u_is_rows = u_is_rows;
     a.cell_key = w->cell_key; a.cell_idx = w->cell_idx; a.klist = w->klist; a.kcell = w->kcell;
     a.out_u = d_out_u; a.out_v = d_out_v; a.out_lin = d_out_lin; a.out_metric = d_out_metric; a.out_count = d_out_count;
-    hipLaunchKernelGGL(k_uniform, dim3(1), dim3(1024), 0, stream, a);
+    hipLaunchKernelGGL(k_uniform, dim3(1), dim3(UNI_NT), 0, stream, a);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }
