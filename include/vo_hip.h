@@ -215,7 +215,9 @@ int vo_dev_select_candidates(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, 
  * enqueued between them (tracking, pose, triangulation), and only the part that needs the existing points
  * (:23-33) runs where vo_dev_select_candidates would.  Results are identical to the single call.
  * max_exist: upper bound of the n_exist that vo_dev_select_finish will pass.  At most two selections may be
- * open; vo_dev_select_finish finishes the oldest.  d_img must stay untouched until that finish has run. */
+ * open; vo_dev_select_finish finishes the oldest.  d_img must stay untouched until that finish has run.  Open
+ * selections own the ctx's two selection work areas: any other selection call on the ctx in between makes the
+ * finish fail with VO_ERR_BAD_ARG rather than return another image's corners. */
 int vo_dev_select_begin(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, const vo_sel_opts* opts, int max_exist);
 int vo_dev_select_finish(vo_ctx* ctx, int u_is_rows, const float* d_eu, const float* d_ev, int n_exist,
                          float* d_out_u, float* d_out_v, int32_t* d_out_lin, double* d_out_metric,
@@ -293,7 +295,8 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
  * coming call's tracking launch, beside the thinly occupied rest of that frame, and the call that processes the
  * announced image (same pointer, same on_device) only waits for them.  Results are identical with and without.
  * The announced image must stay valid and unchanged until the call that processes it has returned; any other
- * image given to that call, vo_frame_set_image or vo_frame_set_state abandon what was issued.  NULL withdraws. */
+ * image given to that call, vo_frame_set_image, vo_frame_set_state, or another selection on the same ctx in
+ * between (a second loop, a stand-alone vo_select_candidates) abandon what was issued.  NULL withdraws. */
 int vo_frame_announce(vo_ctx* ctx, vo_frame_state* st, const uint8_t* next_img, int on_device);
 
 /* ==== frame ingest: imread + rgb2gray + im2uint8 as the reference's frame loops use

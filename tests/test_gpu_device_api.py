@@ -85,6 +85,12 @@ def test_two_call_selection_misuse_is_an_error(ctx):
     with pytest.raises(_lib.VoError):                                   # the queue is empty again
         ctx.call("vo_dev_select_finish", 0, ptr(e), ptr(e), 4, ptr(out), ptr(out), None, None, ptr(cnt))
     ctx.sync()
+    # a single-call selection between begin and finish takes the first work area: that finish says so
+    ctx.call("vo_dev_select_begin", ptr(img), 80, 64, C.byref(o), 4)
+    ctx.call("vo_dev_select_candidates", ptr(img), 80, 64, 0, ptr(e), ptr(e), 4, C.byref(o), ptr(out), ptr(out), None, None, ptr(cnt))
+    with pytest.raises(_lib.VoError):
+        ctx.call("vo_dev_select_finish", 0, ptr(e), ptr(e), 4, ptr(out), ptr(out), None, None, ptr(cnt))
+    ctx.sync()
     with pytest.raises(_lib.VoError):
         ctx.call("vo_dev_select_begin", None, 80, 64, C.byref(o), 4)
 

@@ -226,6 +226,17 @@ def test_look_ahead_changes_nothing_but_the_schedule(ctx, sequence, device_image
             if g0 is not None:
                 assert states_equal(g0, g1)
         assert states_equal(plain_final, other_final)
+    # another selection on the same ctx between the frames takes the work area the look-ahead used every other
+    # frame: that look-ahead is abandoned, the results stay the same
+    from visual_odometry_amd import ops
+    loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=160, ctx=ctx)
+    loop.set_state(st0, imgs[0])
+    for k in range(1, len(imgs)):
+        p, status, info = loop.processFrame(imgs[k], imgs[k + 1] if k + 1 < len(imgs) else None)
+        assert np.array_equal(p, plain[k - 1][0]) and info == plain[k - 1][2], k
+        ops.select_candidates(frames[0], np.zeros((0, 2), np.float32), keep=20, index_base=0, ctx=ctx)
+    assert states_equal(loop.get_state(), plain_final)
+    loop.close()
     # a state load and a new previous image between the announcement and its use
     loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=160, ctx=ctx)
     loop.set_state(st0, imgs[0])

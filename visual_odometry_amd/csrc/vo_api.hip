@@ -20,6 +20,7 @@ struct vo_sel_pending {
         vo_sel_opts o;
         vo_sel_work w;
         hipEvent_t join = nullptr;  // recorded on the side stream behind the detect half
+        int set = 0; uint64_t gen = 0;   // work area and its hand-out number (vo_ctx::sel_gen)
     } q[2];
     int head = 0, count = 0;        // q[head] is the oldest open entry
 };
@@ -104,6 +105,7 @@ void vo_ctx_destroy(vo_ctx* c) {
 int vo_ctx_set_stream(vo_ctx* ctx, void* s) {
     if (!ctx) return VO_ERR_BAD_ARG;
     VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->side) VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->side));
     ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
     return VO_OK;
 }

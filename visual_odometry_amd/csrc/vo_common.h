@@ -45,6 +45,8 @@ struct vo_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     struct vo_sel_pending* sel_pending = nullptr;  // vo_dev_select_begin .. vo_dev_select_finish
+    uint64_t sel_gen[2] = {0, 0};   // bumped whenever a selection work area is handed out: work issued ahead into it
+                                    // (look-ahead, open selections) is valid only while the number stands
     bool resp_attr_set = false;  // k_response's dynamic-LDS limit raised on this context's device (a per-device attribute)
     vo_pyr frames[VO_NUM_FRAME_SLOTS];
     uint64_t clock = 0;

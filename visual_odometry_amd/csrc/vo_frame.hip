@@ -344,6 +344,7 @@ struct vo_frame_state {
     // stream during the vo_frame_process call before its own, behind that call's tracking launch
     const uint8_t* next_src = nullptr; int next_on_device = 0;    // announced, not issued yet
     const uint8_t* ahead_src = nullptr; int ahead_on_device = 0;  // issued into slot (cur + 1) % 3
+    uint64_t ahead_gen = 0;                 // hand-out number of the selection work area it used (vo_ctx::sel_gen)
     hipEvent_t ev_ready = nullptr;          // side stream: copy + pyramid of the look-ahead slot
     hipEvent_t ev_fork_la = nullptr;        // ctx stream: behind the tracking launch
     hipEvent_t ev_detect[2] = {nullptr, nullptr};  // side stream: detect half, per selection work set (frame parity)
@@ -610,7 +611,10 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
     // half were issued back then and only have to be waited for.
     const int set = frame_no & 1;                       // the selection work area of this frame
     vo_sel_work& selw = st->selw[set];
-    const bool ahead = st->ahead_src && st->ahead_src == img && st->ahead_on_device == on_device;
+    // ... unless another selection on this ctx has taken the look-ahead's work area since (another loop, a
+    // stand-alone vo_select_candidates): then it is abandoned like a wrong announcement
+    const bool ahead = st->ahead_src && st->ahead_src == img && st->ahead_on_device == on_device &&
+                       (o.sel.keep <= 0 || ctx->sel_gen[set] == st->ahead_gen);
     if (ahead) {
         ST_CHECK(hipStreamWaitEvent(sm, st->ev_ready, 0));
         st->ahead_src = nullptr;
@@ -718,7 +722,7 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
             if ((rc = vo_launch_select_detect(ctx, ctx->side, st->img[c], st->nu, st->nv, &o.sel, &nw))) return rc;
             ST_CHECK(hipEventRecord(st->ev_detect[1 - set], ctx->side));
         }
-        st->ahead_src = st->next_src; st->ahead_on_device = st->next_on_device;
+        st->ahead_src = st->next_src; st->ahead_on_device = st->next_on_device; st->ahead_gen = ctx->sel_gen[1 - set];
         st->next_src = nullptr;
     }
     ST_CHECK(hipGetLastError());
