@@ -302,6 +302,7 @@ static int frame_from_host(vo_ctx* ctx, const uint8_t* img, int nu, int nv, int 
     }
     vo_pyr* f = &ctx->frames[lru];
     f->valid = false;
+    { int rc = frame_await(ctx, f); if (rc) return rc; }   // a prefetch into this slot may still be running
     if (nbytes > f->img_cap) {
         VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (f->img) (void)hipFree(f->img);
