@@ -122,7 +122,8 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
                      const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
                      const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers,
                      const int32_t* d_M = nullptr,    // d_M: the point count on the device (M is then its upper bound)
-                     int score_all = 0);              // 1: no early exit of the adaptive run (per-hypothesis outputs wanted)
+                     int score_all = 0,               // 1: no early exit of the adaptive run (per-hypothesis outputs wanted)
+                     double* d_pose_out = nullptr);   // optional: the winning pose as [R_WC; t_WC], written by the last kernel
 int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_strides sp, int M, const double* d_K,
                         const vo_ransac_opts* o, const int32_t* d_sample_idx, const double* d_E_in, vo_ransac_work* w,
                         void* d_out, uint8_t* d_inliers);

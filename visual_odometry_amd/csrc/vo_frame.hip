@@ -35,8 +35,7 @@ __device__ __forceinline__ int block_excl_scan_1024(int flag, int* total, int* s
 // ordered compaction in one launch: Op::flag(i) says whether element i stays, Op::move(i, d) puts it at
 // position d of the output; *count = number kept.  One block walks the n elements 1024 at a time.
 template <class Op>
-__global__ __launch_bounds__(1024) void k_compact(Op op, int n, int32_t* count, const int32_t* n_dev = nullptr) {
-    __shared__ int s_w[16];
+__device__ __forceinline__ void compact_block(const Op& op, int n, int32_t* count, const int32_t* n_dev, int* s_w) {
     if (n_dev) n = min(n, *n_dev);   // the count lives on the device, n is its upper bound
     int base = 0;
     for (int i0 = 0; i0 < n; i0 += 1024) {
@@ -48,6 +47,18 @@ __global__ __launch_bounds__(1024) void k_compact(Op op, int n, int32_t* count, 
         base += tot;
     }
     if (threadIdx.x == 0 && count) *count = base;
+}
+template <class Op>
+__global__ __launch_bounds__(1024) void k_compact(Op op, int n, int32_t* count, const int32_t* n_dev = nullptr) {
+    __shared__ int s_w[16];
+    compact_block(op, n, count, n_dev, s_w);
+}
+// two independent compactions in one launch: block 0 does A, block 1 does B
+template <class OpA, class OpB>
+__global__ __launch_bounds__(1024) void k_compact2(OpA a, int na, int32_t* count_a, OpB b, int nb, int32_t* count_b) {
+    __shared__ int s_w[16];
+    if (blockIdx.x == 0) compact_block(a, na, count_a, nullptr, s_w);
+    else compact_block(b, nb, count_b, nullptr, s_w);
 }
 
 // landmarks whose keypoint tracked validly (:280-281): (q, L) -> (vk, vl), pitch = capL
@@ -102,21 +113,23 @@ struct LandmarkOp {
         rep[d] = wrep[i];
     }
 };
-// start of a frame: the per-frame counters and the tombstone array
-__global__ void k_frame_reset(int32_t* counts, uint8_t* alive, int pw) {
+// start of a frame, one launch: the per-frame counters and the tombstone array are cleared, and the frame's two
+// track calls (:278 landmarks, :71 candidates), which share the image pair, get their points in one array
+__global__ void k_frame_begin(int32_t* counts, uint8_t* alive, int pw, int nL, int nC, int capL, int capC, const double* kp,
+                              const double* cu, double* pin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 16) counts[i] = 0;
     if (i < pw) alive[i] = 0;
+    if (i < nL) { pin[i] = kp[i]; pin[pw + i] = kp[capL + i]; }
+    else if (i < nL + nC) { const int c = i - nL; pin[i] = cu[c]; pin[pw + i] = cu[capC + c]; }
 }
-
-// the frame's two track calls (:278 landmarks, :71 candidates) share the image pair: one launch
-__global__ void k_concat_points(int nL, int nC, int capL, int capC, const double* kp, const double* cu, double* pin, int PW) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nL) { pin[i] = kp[i]; pin[PW + i] = kp[capL + i]; }
-    else if (i < nL + nC) { const int c = i - nL; pin[i] = cu[c]; pin[PW + i] = cu[capC + c]; }
-}
-__global__ void k_split_candidates(int nL, int nC, int capC, int PW, const double* q, const uint8_t* valid, double* cq, uint8_t* cvalid) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// after tracking, one launch: block 0 keeps the validly tracked landmarks in order (:280-281), the other blocks
+// split the candidates' results off the shared arrays
+__global__ __launch_bounds__(1024) void k_after_track(TrackedOp top, int nL, int32_t* count, int nC, int capC, int PW,
+                                                      const double* q, const uint8_t* valid, double* cq, uint8_t* cvalid) {
+    __shared__ int s_w[16];
+    if (blockIdx.x == 0) { compact_block(top, nL, count, nullptr, s_w); return; }
+    const int c = (blockIdx.x - 1) * 1024 + threadIdx.x;
     if (c >= nC) return;
     cq[c] = q[nL + c]; cq[capC + c] = q[PW + nL + c];
     cvalid[c] = valid[nL + c];
@@ -631,26 +644,25 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
         }
         if ((rc = build_pyramid(ctx, st, b))) return rc;
     }
-    hipLaunchKernelGGL(k_frame_reset, dim3(blocks(std::max(pw, 16))), dim3(256), 0, sm, st->counts, st->alive, pw);
+    hipLaunchKernelGGL(k_frame_begin, dim3(blocks(std::max(pw, 16))), dim3(256), 0, sm, st->counts, st->alive, pw, nL, nC, cl, cc,
+                       st->kp[s], st->cu[s], st->pin);
 
     // [1] :278-281 and :71 track the landmarks' keypoints and the candidates in one launch; keep the
     // validly tracked landmarks in order
     // The number M of validly tracked landmarks stays on the device (counts[6]): the pose step, the
     // reprojection filter and the compaction are sized by its upper bound nL and read M themselves.
     if (nL + nC > 0) {
-        hipLaunchKernelGGL(k_concat_points, dim3(blocks(nL + nC)), dim3(256), 0, sm, nL, nC, cl, cc, st->kp[s], st->cu[s], st->pin, pw);
         if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->pin, st->pin + pw, nL + nC, o.klt.block_w, o.klt.block_h,
                                 o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, st->score, nullptr))) return rc;
     }
     // look-ahead, part 1: the point of the ctx stream behind which the side stream may start (the tracking launch
     // is the last reader of the slot and of the work area that the look-ahead overwrites)
     if (st->next_src) ST_CHECK(hipEventRecord(st->ev_fork_la, sm));
-    if (nL > 0) {
+    if (nL + nC > 0) {   // with nL == 0 block 0 writes a tracked count of 0, which the frame's clear has put there already
         TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
-        hipLaunchKernelGGL(k_compact<TrackedOp>, dim3(1), dim3(1024), 0, sm, top, nL, st->counts + 6, nullptr);
+        hipLaunchKernelGGL(k_after_track, dim3(1 + blocks(nC, 1024)), dim3(1024), 0, sm, top, nL, st->counts + 6, nC, cc, pw, st->q,
+                           st->valid, st->cq, st->cvalid);
     }
-    if (nC > 0)
-        hipLaunchKernelGGL(k_split_candidates, dim3(blocks(nC)), dim3(256), 0, sm, nL, nC, cc, pw, st->q, st->valid, st->cq, st->cvalid);
     // [2] :285-289 pose (fewer than 4 tracked points: status 1 and the identity, as the toolbox function errors out)
     if (nL >= 4) {
         vo_ransac_opts ro = o.pose;
@@ -658,11 +670,12 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
         vo_ransac_work w;
         if ((rc = vo_int_ransac_work_prepare(ctx, ro.num_hyp, &w))) return rc;
         vo_strides s2 = {1, cl}, s3 = {1, cl};
-        if ((rc = vo_launch_ransac(ctx, st->vk, s2, st->vl, s3, nL, st->K, &ro, nullptr, nullptr, &w, st->rsout, st->inl, st->counts + 6))) return rc;
+        if ((rc = vo_launch_ransac(ctx, st->vk, s2, st->vl, s3, nL, st->K, &ro, nullptr, nullptr, &w, st->rsout, st->inl, st->counts + 6, 0,
+                                   pose_now))) return rc;   // the pose step's last kernel also writes the pose (:318)
     } else {
         hipLaunchKernelGGL(k_identity_record, dim3(1), dim3(1), 0, sm, st->rsout, 1);
+        hipLaunchKernelGGL(k_pose_from_rt, dim3(1), dim3(1), 0, sm, st->rsout, pose_now);
     }
-    hipLaunchKernelGGL(k_pose_from_rt, dim3(1), dim3(1), 0, sm, st->rsout, pose_now);
     // [3] :298-315 reprojection error, strict filter, survivors into the merge arrays
     if (nL > 0) {
         vo_strides s2 = {1, cl}, s3 = {1, cl};
@@ -689,11 +702,14 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
             hipLaunchKernelGGL(k_merge_rank, dim3(blocks(16 * (nL + nC))), dim3(256), 0, sm, mw);
             hipLaunchKernelGGL(k_merge_write, dim3(1), dim3(1024), 0, sm, mw);
         }
+        // the aged candidates and the final landmark order are independent: one launch, a block each
         CandOp cop = {ca, cc, st->cq, st->cf[s], st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]};
-        hipLaunchKernelGGL(k_compact<CandOp>, dim3(1), dim3(1024), 0, sm, cop, nC, st->counts + 1, nullptr);
+        LandmarkOp lop = {st->alive, pw, cl, st->wkp, st->wL, st->wrep, st->kp[n], st->L[n], st->rep[n]};
+        hipLaunchKernelGGL((k_compact2<CandOp, LandmarkOp>), dim3(2), dim3(1024), 0, sm, cop, nC, st->counts + 1, lop, pw, st->counts + 0);
+    } else {
+        LandmarkOp lop = {st->alive, pw, cl, st->wkp, st->wL, st->wrep, st->kp[n], st->L[n], st->rep[n]};
+        hipLaunchKernelGGL(k_compact<LandmarkOp>, dim3(1), dim3(1024), 0, sm, lop, pw, st->counts + 0, nullptr);
     }
-    LandmarkOp lop = {st->alive, pw, cl, st->wkp, st->wL, st->wrep, st->kp[n], st->L[n], st->rep[n]};
-    hipLaunchKernelGGL(k_compact<LandmarkOp>, dim3(1), dim3(1024), 0, sm, lop, pw, st->counts + 0, nullptr);
     // [5b] :330-345 new candidates away from every tracked point; the number of existing points stays on the
     // device (counts[0] + counts[1]), so the host does not wait here
     hipLaunchKernelGGL(k_existing, dim3(blocks(pw)), dim3(256), 0, sm, st->counts, cl, cc, st->kp[n], st->cu[n], st->eu, st->ev);

@@ -514,10 +514,16 @@ struct InlArgs {
     const double* xy; vo_strides sxy; const double* X; vo_strides sX; int M; const double* K; double thr2;
     double* out; uint8_t* inliers;
     const int32_t* M_dev;   // as in HypArgs (flags beyond the device count are written as 0)
+    double* pose_out;       // optional: the pose [R_WC; t_WC] of the record (modules/VisualOdometry.m:318), C = -R_cw^T t_cw
 };
 __global__ __launch_bounds__(256) void k_inliers(InlArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     int32_t* info = (int32_t*)(a.out + 12);
+    if (i == 0 && a.pose_out) {
+        const double* out = a.out;
+        for (int k = 0; k < 9; ++k) a.pose_out[k] = out[k];
+        for (int c = 0; c < 3; ++c) a.pose_out[9 + c] = -((out[c] * out[9] + out[3 + c] * out[10]) + out[6 + c] * out[11]);
+    }
     bool in = false;
     const int Md = a.M_dev ? min(a.M, *a.M_dev) : a.M;
     if (i < Md && info[0] == 0) {
@@ -546,7 +552,8 @@ __global__ __launch_bounds__(64) void k_p3p_batch(const double* P, const double*
 
 int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int M,
                      const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
-                     const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers, const int32_t* d_M, int score_all) {
+                     const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers, const int32_t* d_M, int score_all,
+                     double* d_pose_out) {
     const int H = o->num_hyp;
     if (H < 1 || M < 4 || !(o->max_reproj_err > 0)) { ctx->last_error = "ransac: need num_hyp >= 1, M >= 4, max_reproj_err > 0"; return VO_ERR_BAD_ARG; }
     if (o->mode != 0 && o->mode != 1) { ctx->last_error = "ransac: mode must be 0 or 1"; return VO_ERR_BAD_ARG; }
@@ -577,7 +584,7 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
     }
     InlArgs in;
     in.xy = d_xy; in.sxy = sxy; in.X = d_X; in.sX = sX; in.M = M; in.K = d_K; in.thr2 = thr2; in.out = (double*)d_out;
-    in.inliers = d_inliers; in.M_dev = d_M;
+    in.inliers = d_inliers; in.M_dev = d_M; in.pose_out = d_pose_out;
     hipLaunchKernelGGL(k_inliers, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, in);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
