@@ -69,6 +69,25 @@ def cpu_baseline(args, frames, budget_s=12.0, max_frames=24):
                       f"triangulation {parts['triangulate']:.1f} s, selection {parts['select']:.1f} s), nothing scaled"}
 
 
+def small_workload_leg(ctx, args, FrameWorkload, keypoints=2000, steps=300):
+    """Extra leg: the same step at BASELINE configs[1]'s size (KITTI shape, ~2k KLT keypoints), the low end of the
+    sweep in profiles/round1_keypoint_sweep.txt; the headline stays the stress size, where the kernels are
+    throughput-bound and keypoints/s means something."""
+    wl = FrameWorkload(ctx, keypoints // 2, keypoints - keypoints // 2, num_hyp=args.hyp, seed=4099)
+    for _ in range(100):
+        wl.step()
+    wl.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    wl.sync()
+    dt = time.perf_counter() - t0
+    wl.drain(); wl.sync()
+    return {"keypoints_per_frame": keypoints, "hypotheses": args.hyp, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "frames_per_s": steps / dt, "value": keypoints * steps / dt, "unit": "keypoints/s",
+            "workload": "the bench step with 2000 keypoints per frame (1000 landmarks + 1000 candidates), everything else as in config"}
+
+
 def frame_loop_leg(ctx, with_cpu, n_frames=24):
     """Extra leg: the device-resident VisualOdometry.processFrame loop at the
     reference's own sizes (300 landmarks, 100 new candidates per frame, <= 5000 trials at 99 %) on a
@@ -311,6 +330,7 @@ def main():
             frames = [f.cpu().numpy() for f in wl.frames[:5]]
             line["cpu_baseline"] = cpu_baseline(args, frames)
         if not args.no_frame_loop and world == 1:         # extra legs: one GPU, while no other rank waits
+            line["at_2k_keypoints"] = small_workload_leg(ctx, args, FrameWorkload)
             line["frame_loop"] = frame_loop_leg(ctx, not args.no_cpu)
         print(json.dumps(line))
     dist.barrier()
