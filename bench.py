@@ -220,6 +220,26 @@ def main():
     ap.add_argument("--no-frame-loop", action="store_true", help="skip the device-resident processFrame leg")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` outside a launcher: this process starts the N ranks itself (before torch is imported
+    # or any GPU call is made -- the parent never holds a HIP context) and relays their verdict.
+    from visual_odometry_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
+    if os.environ.get("VO_BENCH_RENDEZVOUS_ONLY"):
+        # CPU rehearsal of the N-rank start (tests/test_dist_cpu.py): rendezvous over gloo, the statistics
+        # collective, one line from rank 0 -- and nothing that needs a GPU
+        from visual_odometry_amd import dist
+        rank, local_rank, world = dist.init("gloo")
+        if world != args.gpus:
+            sys.exit(2)
+        dist.barrier()
+        stats = dist.gather_stats({"frames": 1, "keypoints_tracked": args.keypoints, "elapsed_s": 1.0 + rank})
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "n_gpus": world, "frames": stats["frames"], "elapsed_s": stats["elapsed_s"]}))
+        dist.shutdown()
+        return
+
     import torch
     from visual_odometry_amd import _lib, dist
     from visual_odometry_amd.device import FrameWorkload

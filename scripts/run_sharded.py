@@ -3,9 +3,10 @@
 end (loader -> bootstrap -> decode pool -> device-resident frame loop -> trajectory), one collective at the end
 for the statistics.  No data-path exchange: frames of a sequence are a Markov chain.
 
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/run_sharded.py \\
-        kitti <root with 00..10/image_0 and poses/> [frames per sequence]
-    ... scripts/run_sharded.py synthetic <n_sequences> [frames per sequence]     # rendered parking-layout trees
+    python scripts/run_sharded.py --gpus N kitti <root with 00..10/image_0 and poses/> [frames per sequence]
+    python scripts/run_sharded.py --gpus N synthetic <n_sequences> [frames per sequence]   # rendered parking-layout trees
+(the script starts its N ranks itself, visual_odometry_amd/launch.py; under torch.distributed.run it takes the
+launcher's ranks instead and --gpus is not needed)
 VO_REHEARSE_ONE_GPU=1 puts every rank on device 0 with gloo (a rehearsal of the N > 1 path on a one-GPU box).
 """
 import json
@@ -14,7 +15,16 @@ import sys
 import tempfile
 import time
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from visual_odometry_amd import launch
+
+if "--gpus" in sys.argv:                            # start the ranks from here, before torch or the GPU is touched
+    k = sys.argv.index("--gpus")
+    n_gpus = int(sys.argv[k + 1])
+    del sys.argv[k:k + 2]
+    if not launch.under_launcher():
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], n_gpus))
+
 rehearse = bool(os.environ.get("VO_REHEARSE_ONE_GPU"))
 if not rehearse:
     os.environ["VO_USE_LOCAL_RANK"] = "1"          # Context.default() = this rank's GPU

@@ -4,6 +4,7 @@
 // `iters` damaged copies of it are decoded: each must end in VO_OK or an error code, never in a sanitizer report.
 //
 //   decode_fuzz <iters> <seed> file...
+//   decode_fuzz refuse file...      crafted bad files: each must be refused with an error code (no write, no report)
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -69,8 +70,28 @@ int decode_once(const std::vector<uint8_t>& b, DecodeScratch* sc, std::vector<ui
 }  // namespace
 
 int main(int argc, char** argv) {
+    if (argc >= 3 && strcmp(argv[1], "refuse") == 0) {
+        DecodeScratch sc;
+        std::vector<uint8_t> buf, out;
+        for (int f = 2; f < argc; ++f) {
+            std::string err;
+            size_t n = 0;
+            if (vo_dec_read_file(argv[f], &buf, &n, &err) != VO_OK) {
+                fprintf(stderr, "%s: %s\n", argv[f], err.c_str());
+                return 1;
+            }
+            buf.resize(n);
+            const int rc = decode_once(buf, &sc, &out, &err);
+            if (rc >= 0) {
+                fprintf(stderr, "%s: decoded with status %d, expected an error\n", argv[f], rc);
+                return 1;
+            }
+            printf("%s: refused (%d) %s\n", argv[f], rc, err.c_str());
+        }
+        return 0;
+    }
     if (argc < 4) {
-        fprintf(stderr, "usage: decode_fuzz <iters> <seed> file...\n");
+        fprintf(stderr, "usage: decode_fuzz <iters> <seed> file... | decode_fuzz refuse file...\n");
         return 2;
     }
     const long iters = atol(argv[1]);

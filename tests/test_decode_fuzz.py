@@ -70,3 +70,47 @@ def test_damaged_files_end_in_a_return_code(harness, tmp_path, seed):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     decoded, refused = [int(w) for w in r.stdout.split() if w.isdigit()]
     assert decoded > 0 and refused > 0        # both outcomes were exercised
+
+
+def _segments(jpg):
+    """(marker, start, end) of the header segments of a baseline JPEG up to and including SOS."""
+    pos, out = 2, []
+    while pos < len(jpg):
+        assert jpg[pos] == 0xFF
+        m = jpg[pos + 1]
+        ln = int.from_bytes(jpg[pos + 2:pos + 4], "big")
+        out.append((m, pos, pos + 2 + ln))
+        pos += 2 + ln
+        if m == 0xDA:
+            break
+    return out
+
+
+def crafted_bad_jpegs(tmp_path):
+    """Files a fuzzer finds slowly: (1) a second SOF0 four times the size behind the first -- the header the caller
+    sizes `out` from is the first, a decoder that lets the second one win writes past it; (2) the scan
+    cut in the middle and closed with EOI -- the rest of the frame would decode from zero fill; (3) a stray non-RST
+    marker in the middle of the scan."""
+    good = open(os.path.join(JPEG_DIR, "gray_q75.jpg"), "rb").read()
+    segs = _segments(good)
+    sof = next(s for s in segs if s[0] == 0xC0)
+    sos = next(s for s in segs if s[0] == 0xDA)
+    seg = bytearray(good[sof[1]:sof[2]])
+    h, w = int.from_bytes(seg[5:7], "big"), int.from_bytes(seg[7:9], "big")
+    seg[5:7] = (2 * h).to_bytes(2, "big"); seg[7:9] = (2 * w).to_bytes(2, "big")
+    two_sof = good[:sof[2]] + bytes(seg) + good[sof[2]:]
+    body = good[sos[2]:-2]
+    early_eoi = good[:sos[2]] + body[:len(body) // 2] + b"\xff\xd9"
+    stray = good[:sos[2]] + body[:len(body) // 3] + b"\xff\xe1\x00\x02" + body[len(body) // 3:] + b"\xff\xd9"
+    paths = []
+    for name, data in (("two_sof.jpg", two_sof), ("early_eoi.jpg", early_eoi), ("stray_marker.jpg", stray)):
+        p = tmp_path / name
+        p.write_bytes(data)
+        paths.append(str(p))
+    return paths
+
+
+def test_crafted_bad_jpegs_are_refused(harness, tmp_path):
+    r = subprocess.run([harness, "refuse"] + crafted_bad_jpegs(tmp_path), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "more than one frame header" in r.stdout and r.stdout.count("ends before the last MCU") == 2, r.stdout

@@ -1,6 +1,9 @@
 """The N > 1 path on CPU: two gloo ranks run the statistics gather and the sequence assignment."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import torch.multiprocessing as mp
 
@@ -52,3 +55,34 @@ def test_assignment_is_balanced_and_deterministic():
 def test_single_process_gather_is_identity():
     out = dist.gather_stats({"frames": 3, "elapsed_s": 0.5})
     assert out["frames"] == 3 and out["elapsed_s"] == 0.5 and out["world"] == 1
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns two ranks (before anything touches a
+    GPU), they meet over gloo, run the statistics collective, and rank 0's line comes back through the parent."""
+    env = dict(os.environ, VO_BENCH_RENDEZVOUS_ONLY="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--keypoints", "123"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # one line, from rank 0
+    out = json.loads(lines[0])
+    assert out["rendezvous"] == "ok" and out["n_gpus"] == 2 and out["frames"] == 2 and out["elapsed_s"] == 2.0
+
+
+def test_a_failing_rank_fails_the_launch(tmp_path):
+    """One rank exits non-zero before the rendezvous: the launcher stops the other one and reports failure."""
+    from visual_odometry_amd import launch
+    script = tmp_path / "ranks.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(3)\n"
+                      "time.sleep(60)\n")
+    import time
+    t0 = time.time()
+    assert launch.spawn_ranks(str(script), [], 2, grace_s=2.0) == 3
+    assert time.time() - t0 < 30

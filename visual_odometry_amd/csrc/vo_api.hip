@@ -9,7 +9,8 @@
 
 // scratch buffer purposes
 enum { SB_PU = 0, SB_PV, SB_QU, SB_QV, SB_VALID, SB_SCORE, SB_IMG, SB_A, SB_B, SB_C, SB_D, SB_E, SB_F, SB_G, SB_H, SB_I,
-       SB_RGB = 16, SB_A2 = 17 };
+       SB_RGB = 16, SB_A2 = 17,
+       SB_RESP = 18 };   // response / greedy entry points: never a selection work area (those are guarded by sel_gen only)
 
 // Selections begun and not yet finished (vo_dev_select_begin / vo_dev_frame_prefetch .. vo_dev_select_finish):
 // a queue of at most two, each with its own work buffers (set 0: scratch[SB_A], set 1: scratch[SB_A2]) and its
@@ -43,6 +44,7 @@ int vo_buf_reserve(vo_ctx* ctx, vo_buf* b, size_t bytes) {
     if (bytes <= b->cap) return VO_OK;
     if (b->p) {
         VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->side) VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->side));   // work issued ahead may still read the old block
         VO_HIP_CHECK(ctx, hipFree(b->p));
         b->p = nullptr; b->cap = 0;
     }

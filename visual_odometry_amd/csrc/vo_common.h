@@ -51,7 +51,7 @@ struct vo_ctx {
     vo_pyr frames[VO_NUM_FRAME_SLOTS];
     uint64_t clock = 0;
     unsigned long long* d_counters = nullptr; // VO_COUNTER_SHARDS x 4 u64
-    vo_buf scratch[18];                        // purpose-indexed scratch (see vo_api.hip; [16] = vo_rgb2gray staging, [17] = second selection set)
+    vo_buf scratch[20];                        // purpose-indexed scratch (see vo_api.hip; [16] = vo_rgb2gray staging, [17] = second selection set, [18] = response / greedy entry points)
     std::string last_error;
 };
 

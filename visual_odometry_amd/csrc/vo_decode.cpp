@@ -350,9 +350,14 @@ int image_decode(const uint8_t* d, size_t n, const ImgHdr& h, uint8_t* out, Deco
     if (h.kind == 1) return png_decode(d, n, h, out, sc, err);
     if (h.kind == 2) return pnm_decode(d, n, h, out);
     if (h.kind == 3) {
-        JpegFrame f;
+        JpegFrame f{};
         int rc = vo_jpeg_layout(d, n, &f, err);
         if (rc != VO_OK) return rc;
+        // `out` was sized from the header the caller parsed: the frame decoded here must be that frame
+        if (f.W != h.W || f.H != h.H || f.nc != h.channels || (uint64_t)f.W * f.H > VO_DEC_MAX_PIXELS) {
+            *err = "jpeg: frame geometry differs from the header";
+            return VO_ERR_BAD_ARG;
+        }
         if (sc->coef.size() < f.nblocks * 64) sc->coef.resize(f.nblocks * 64);
         rc = vo_jpeg_entropy(d, n, &f, sc->coef.data(), err);
         if (rc != VO_OK) return rc;

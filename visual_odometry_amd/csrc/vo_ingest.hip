@@ -297,8 +297,14 @@ void ingest_worker(vo_ingest* g) {
         if (rc == VO_OK) rc = vo_dec_header(sc.file.data(), fn, &h, &err);
         if (rc == VO_OK && h.kind == 3) {
             // JPEG: the bit stream is decoded here, everything after it on the device
-            JpegFrame f;
+            JpegFrame f{};
             rc = vo_jpeg_layout(sc.file.data(), fn, &f, &err);
+            // the sizes below come from this second parse: hold it to the header's (pixel cap included)
+            if (rc == VO_OK && (f.W != h.W || f.H != h.H || f.nc != h.channels || (uint64_t)f.W * f.H > VO_DEC_MAX_PIXELS)) {
+                rc = VO_ERR_BAD_ARG;
+                err = "jpeg: frame geometry differs from the header";
+            }
+            if (rc != VO_OK) f = JpegFrame{};
             const size_t raw_bytes = f.nblocks * 64 * sizeof(int16_t);
             const int och = (f.nc == 1 || g->to_gray) ? 1 : 3;
             if (rc == VO_OK && s->uploaded && hipEventSynchronize(s->ready) != hipSuccess) rc = VO_ERR_HIP;

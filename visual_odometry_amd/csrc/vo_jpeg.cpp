@@ -47,6 +47,8 @@ struct Bits {
     uint64_t acc = 0;
     int cnt = 0;
     int marker = 0;  // a marker met in the entropy data: zeros are fed from there on
+    int fake = 0;    // how many of the cnt bits in acc are such zeros (behind a marker or the end of the buffer)
+    bool overrun = false;  // a code or value was read out of those zeros: the data ended before the decoder did
 
     void fill() {
         if (cnt <= 32 && !marker && p + 4 <= end) {  // four plain bytes at once when none of them is 0xff
@@ -60,14 +62,17 @@ struct Bits {
         }
         while (cnt <= 56) {
             unsigned b = 0;
+            bool real = false;
             if (!marker && p < end) {
                 b = *p;
+                real = true;
                 if (b == 0xff) {
                     const unsigned b2 = p + 1 < end ? p[1] : 0xd9;
                     if (b2 == 0) p += 2;  // stuffed zero
                     else {
                         marker = (int)b2;
                         b = 0;
+                        real = false;
                     }
                 } else {
                     ++p;
@@ -75,12 +80,17 @@ struct Bits {
             }
             acc |= (uint64_t)b << (56 - cnt);
             cnt += 8;
+            if (!real) fake += 8;
         }
     }
     unsigned peek(int n) const { return (unsigned)(acc >> (64 - n)); }
     void skip(int n) {
         acc <<= n;
         cnt -= n;
+        if (cnt < fake) {  // bits taken from the zero fill
+            overrun = true;
+            fake = cnt;
+        }
     }
     int receive_extend(int s) {
         if (s == 0) return 0;
@@ -108,6 +118,7 @@ struct Bits {
     bool restart() {
         acc = 0;
         cnt = 0;
+        fake = 0;
         if (!marker) {
             while (p + 1 < end && !(p[0] == 0xff && p[1] != 0 && p[1] != 0xff)) ++p;
             if (p + 1 >= end) return false;
@@ -177,6 +188,9 @@ int parse(const uint8_t* d, size_t n, Parsed* P, bool header_only, std::string* 
         const uint8_t* s = d + pos + 2;
         const size_t sl = len - 2;
         if (m == 0xc0 || m == 0xc1) {
+            // one frame per file: a later SOF would re-size the frame behind the header the caller sized its
+            // buffers from (vo_jpeg_header returns at the first one)
+            if (P->have_sof) return fail(err, "more than one frame header");
             if (sl < 6) return fail(err, "bad SOF");
             if (s[0] != 8) return fail(err, "only 8-bit samples are decoded", VO_ERR_UNSUPPORTED);
             JpegFrame& f = P->f;
@@ -316,6 +330,9 @@ int vo_jpeg_entropy(const uint8_t* d, size_t n, JpegFrame* out, int16_t* coef, s
     int until_restart = P.ri;
     for (int my = 0; my < mcuy; ++my) {
         for (int mx = 0; mx < mcux; ++mx) {
+            // a marker (an early EOI, a stray segment) or the end of the buffer in the middle of the scan: the
+            // reader feeds zeros from there, and an MCU decoded out of them is not image data
+            if (br.overrun) return fail(err, "entropy-coded data ends before the last MCU");
             if (P.ri && until_restart == 0) {
                 if (!br.restart()) return fail(err, "restart marker missing");
                 pred[0] = pred[1] = pred[2] = 0;
@@ -352,6 +369,7 @@ int vo_jpeg_entropy(const uint8_t* d, size_t n, JpegFrame* out, int16_t* coef, s
             --until_restart;
         }
     }
+    if (br.overrun) return fail(err, "entropy-coded data ends before the last MCU");
     br.fill();
     if (!br.marker) return fail(err, "entropy-coded data truncated");  // a complete scan is followed by a marker (EOI)
     *out = f;
