@@ -158,3 +158,52 @@ def test_steps_with_work_issued_ahead_equal_serial_steps(ctx):
         ahead.select(1); ahead.sync()
     finally:
         other.close()
+
+
+def test_response_entry_points_leave_open_selections_alone(ctx):
+    """vo_corner_response / vo_harris_response / vo_select_keypoints_greedy used to stage through the scratch buffer
+    that is also selection work area 0: called between begin and finish they overwrote the detect results (and with a
+    larger image freed the block under the pending kernels).  They have a slot of their own now: an open selection
+    -- and a frame loop with an announced look-ahead -- gives the same bits with such calls in between."""
+    import torch
+    from visual_odometry_amd import ops
+    from visual_odometry_amd.frame import FrameLoop
+    from oracle import vo_frame
+    nv, nu = 150, 200
+    img = synth.frame_pair(nv=nv, nu=nu, seed=71)[0]
+    big = synth.frame_pair(nv=400, nu=640, seed=72)[0]              # larger than anything this ctx's slot has held
+    pu, pv = synth.keypoints(100, nv=nv, nu=nu, seed=73, border=5)
+    ex = np.stack([pu, pv], 1)
+    d = torch.from_numpy(img).cuda()
+    want = _run(ctx, torch, d, ex, 50, False)
+
+    def between():
+        r1 = ops.corner_response(big, "mineigen", 5, ctx=ctx)
+        r2 = ops.corner_response(big, "harris", 9, 0.08, ctx=ctx)
+        ops.select_keypoints_greedy(r2, 20, 8, ctx=ctx)
+        assert np.array_equal(r1, oracle.corner_response(big, 0, 5))
+    got = _run(ctx, torch, d, ex, 50, True, between=between)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    # inside a frame loop with the next frame announced (its detect half is in flight on work area 0 or 1)
+    K = np.array([[300.0, 0, 160.0], [0, 300.0, 120.0], [0, 0, 1.0]])
+    frames, poses, lift = synth.plane_sequence(5, K)
+    u, v, _, _ = oracle.select_candidates(frames[0], np.zeros(0, np.float32), np.zeros(0, np.float32), min_distance=7, keep=80)
+    st = vo_frame.new_state()
+    st.keypoints = np.stack([u, v], 1).astype(np.float64); st.landmarks = lift(u.astype(np.float64), v.astype(np.float64))
+    st.reproError = np.zeros(len(u))
+    runs = []
+    for disturb in (False, True):
+        loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=100, ctx=ctx)
+        loop.set_state(st, frames[0])
+        out = []
+        for k in range(1, len(frames)):
+            pose, status, info = loop.processFrame(frames[k], frames[k + 1] if k + 1 < len(frames) else None)
+            if disturb:
+                ops.corner_response(big, "harris", 9, 0.08, ctx=ctx)
+            s = loop.get_state()
+            out.append((pose, status, s.keypoints, s.candidate_keypoints, s.landmarks))
+        loop.close()
+        runs.append(out)
+    for a, b in zip(*runs):
+        assert a[1] == b[1] and all(np.array_equal(x, y) for x, y in zip(a[2:], b[2:])) and np.array_equal(a[0], b[0])

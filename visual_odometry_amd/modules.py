@@ -11,6 +11,7 @@ N x 2 `[x y]` with 1-based pixel coordinates, poses are 4 x 3 `[R_WC; t_WC]`
     KLTTracker                  modules/KLTTracker.m:1-43
     selectCandidateKeypoints    modules/selectCandidateKeypoints.m:1-36
     candidateTriangulation      modules/candidateTriangulation.m:1-117 (free function)
+    updateW2D3D                 modules/updateW2D3D.m:1-46 (legacy pose step that keeps the MSAC inliers)
     VisualOdometry              modules/VisualOdometry.m (processFrame :264-346, candidateTriangulation :63-151)
     estimateWorldCameraPose     the toolbox call of modules/VisualOdometry.m:285-289
     calculateAngleDeg           utils/calculateAngleDeg.m:1-11
@@ -160,6 +161,22 @@ def candidateTriangulation(prev_img, prev_state, curr_img, curr_pose, camera_par
     cs.candidate_first_poses = cfp; cs.candidate_time_indxs = np.array(cti, np.int64)
     del cs.reproError
     return cs, tracked_keypoints
+
+
+def updateW2D3D(prev_img, curr_img, prev_state, camera_parameters, tracker, Seed=1023):
+    """[landmarks, keypoints, curr_pose] = updateW2D3D(prev_img, curr_img, prev_state, camera_parameters, tracker)
+    (modules/updateW2D3D.m:1-46): the first-generation pose step.  Track the landmarks' keypoints (:9-11), pose by
+    estimateWorldCameraPose with MaxReprojectionError 1, Confidence 99, MaxNumTrials 10000 (:17-22), and -- unlike
+    VisualOdometry.processFrame -- keep exactly the MSAC inliers among the tracked points (:26-30).  The figures of
+    :13-14,34-42 are not drawn."""
+    curr_pts, val_idx, _ = tracker.track(prev_img, curr_img, prev_state.keypoints)
+    R_WC, T_WC, inl_idx, _ = estimateWorldCameraPose(np.asarray(curr_pts, np.float64)[val_idx],
+                                                     np.asarray(prev_state.landmarks, np.float64)[val_idx],
+                                                     camera_parameters, MaxReprojectionError=1, Confidence=99,
+                                                     MaxNumTrials=10000, Seed=Seed)
+    val = np.flatnonzero(val_idx)
+    keep = val[np.flatnonzero(inl_idx)]
+    return np.asarray(prev_state.landmarks)[keep], np.asarray(curr_pts)[keep], np.vstack([R_WC, T_WC])
 
 
 class VisualOdometry:
