@@ -31,7 +31,7 @@ for tag, kw in (("s", dict(levels=3, wu=21, wv=21, max_iters=30, max_bidir=1.0))
                 ("m", dict(levels=2, wu=31, wv=25, max_iters=30, max_bidir=-1.0))):
     qu, qv, valid, score, fb, iters = oracle.klt_track(img1, img2, pu, pv, **kw)
     out.update({f"klt_{tag}_qu": qu, f"klt_{tag}_qv": qv, f"klt_{tag}_valid": valid, f"klt_{tag}_score": score,
-                f"klt_{tag}_iters": iters})
+                f"klt_{tag}_iters": iters, f"klt_{tag}_fb": fb})
 
 # ---- selection
 sel_img, _, _ = synth.frame_pair(nv=96, nu=128, seed=23)

@@ -43,7 +43,7 @@ def sequential_free_function(prev, kt, val_key, ct, val_cand, curr_pose, K, reca
     """modules/candidateTriangulation.m:17-116 line by line, geometry from the oracle (one candidate at a time)."""
     landmarks = list(np.asarray(prev.landmarks)[val_key]); keypoints = list(kt[val_key])              # :21-22
     ck, cfk, cfp, cti = [], [], [], []
-    n_promoted = n_expired = 0
+    n_promoted = n_expired = n_dropped = 0
     for i in np.flatnonzero(val_cand):                                                                # :37
         pose0 = np.asarray(prev.candidate_first_poses[i])
         X, rep, ang, ok = oracle.triangulate(prev.candidate_first_keypoints[i][None], ct[i][None], pose0[None], curr_pose, K)
@@ -53,6 +53,7 @@ def sequential_free_function(prev, kt, val_key, ct, val_cand, curr_pose, K, reca
         if ang[0] > angle_thr:                                                                        # :86-87
             if len(landmarks) >= cap:                                                                 # :88-91 FIFO
                 landmarks = landmarks[1:]; keypoints = keypoints[1:]
+                n_dropped += 1
             landmarks.append(X[0]); keypoints.append(ct[i])                                           # :92-93
             n_promoted += 1
         elif prev.candidate_time_indxs[i] > -recall:                                                  # :96
@@ -61,7 +62,7 @@ def sequential_free_function(prev, kt, val_key, ct, val_cand, curr_pose, K, reca
         else:
             n_expired += 1
     return (np.array(landmarks).reshape(-1, 3), np.array(keypoints).reshape(-1, 2), np.array(ck).reshape(-1, 2),
-            np.array(cfk).reshape(-1, 2), cfp, np.array(cti, np.int64), n_promoted, n_expired)
+            np.array(cfk).reshape(-1, 2), cfp, np.array(cti, np.int64), n_promoted, n_expired, n_dropped)
 
 
 @pytest.mark.parametrize("cap,recall", [(500, 50), (120, 3)])
@@ -78,7 +79,7 @@ def test_free_candidateTriangulation_on_the_device(evolved, cap, recall):
     kt, val_key, _ = tracker.track(frames[5], frames[6], prev.keypoints)            # the same device tracks
     ct, val_cand, _ = tracker.track(frames[5], frames[6], prev.candidate_keypoints)
     assert val_key.sum() > 50 and val_cand.sum() > 50
-    lm, kp, ck, cfk, cfp, cti, n_promoted, n_expired = sequential_free_function(prev, kt, val_key, ct, val_cand, pose6, K1, recall, 2.5, cap, 2)
+    lm, kp, ck, cfk, cfp, cti, n_promoted, n_expired, n_dropped = sequential_free_function(prev, kt, val_key, ct, val_cand, pose6, K1, recall, 2.5, cap, 2)
     np.testing.assert_array_equal(tracked, ct[val_cand])                            # :29
     assert not hasattr(out, "reproError")                                           # the free function keeps none
     assert len(out.landmarks) == len(lm) and len(out.candidate_keypoints) == len(ck)
@@ -90,12 +91,13 @@ def test_free_candidateTriangulation_on_the_device(evolved, cap, recall):
     assert len(out.candidate_first_poses) == len(cfp) and all(np.array_equal(a, b) for a, b in zip(out.candidate_first_poses, cfp))
     assert n_promoted > 0
     if cap == 120:
-        assert len(lm) == cap and int(val_key.sum()) + n_promoted > cap             # the FIFO ran (:88-91)
-        assert n_expired > 0                                                        # old candidates expired (:96)
-        # FIFO: the survivors are the LAST `cap` of [tracked landmarks; promoted candidates], oldest dropped first
-        np.testing.assert_array_equal(out.keypoints[:cap - n_promoted], kt[val_key][-(cap - n_promoted):])
+        n0 = int(val_key.sum())
+        assert n_dropped > 0 and len(lm) == n0 + n_promoted - n_dropped             # the FIFO ran (:88-91): at or above
+        assert n_expired > 0                                                        # the cap one goes for each that comes
+        # FIFO: the OLDEST landmarks went, the tracked ones that stay keep their order in front of the promoted
+        np.testing.assert_array_equal(out.keypoints[:n0 - n_dropped], kt[val_key][n_dropped:])
     else:
-        assert len(lm) == int(val_key.sum()) + n_promoted and n_expired == 0
+        assert len(lm) == int(val_key.sum()) + n_promoted and n_expired == 0 and n_dropped == 0
 
 
 def test_free_function_gates_on_world_Z(ctx):

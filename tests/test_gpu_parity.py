@@ -12,6 +12,21 @@ from tests.test_golden import KLT_CFG, SEL_CFG
 pytestmark = pytest.mark.gpu
 K = synth.KITTI_K
 PX_TOL = 0.01  # pixels, north_star
+FB_TOL = 1e-3  # pixels: validity may differ from the oracle's only where the forward-backward error sits this close to
+               # MaxBidirectionalError (measured on every scenario below: no disagreement at all, scripts/klt_disagree.py)
+
+
+def assert_validity(valid, ovalid, ofb, max_bidir, min_both):
+    """Validity against the oracle's: equal, except for points whose forward-backward error (the oracle's) lies
+    within FB_TOL of the threshold -- the only place where fp32 against fp64 arithmetic may legitimately flip it.
+    Returns the mask of points valid on both sides, which must hold at least `min_both` points."""
+    dis = valid != ovalid
+    if dis.any():
+        assert max_bidir >= 0 and (np.abs(ofb[dis] - max_bidir) < FB_TOL).all(), \
+            f"{dis.sum()} validity flips away from the threshold: fb = {ofb[dis][:8]}"
+    both = valid & ovalid
+    assert both.sum() >= min_both, f"only {both.sum()} points are valid on both sides"
+    return both
 
 
 def klt_gpu(img1, img2, pu, pv, levels, wu, wv, max_iters, max_bidir, col_major=False):
@@ -32,10 +47,7 @@ def test_klt_matches_golden(ctx, golden, tag, col_major):
     g, kw = golden, KLT_CFG[tag]
     qu, qv, valid, score = klt_gpu(g["klt_img1"], g["klt_img2"], g["klt_pu"], g["klt_pv"], kw["levels"], kw["wu"],
                                    kw["wv"], kw["max_iters"], kw["max_bidir"], col_major)
-    gv = g[f"klt_{tag}_valid"]
-    assert (valid == gv).mean() >= 0.97                   # a forward-backward error ON the threshold may flip
-    both = valid & gv
-    assert both.sum() > 10
+    both = assert_validity(valid, g[f"klt_{tag}_valid"], g[f"klt_{tag}_fb"], kw["max_bidir"], 40)
     d = np.hypot(qu - g[f"klt_{tag}_qu"], qv - g[f"klt_{tag}_qv"])
     assert d[both].max() < PX_TOL
     assert np.abs(score - g[f"klt_{tag}_score"])[both].max() < 1e-3
@@ -85,9 +97,8 @@ def test_klt_kitti_size_against_oracle_and_truth(ctx):
     err = np.hypot(qu - tu, qv - tv)
     assert valid.mean() > 0.99 and np.median(err[valid]) < 0.03 and np.percentile(err[valid], 99) < 0.1
     n = 1500
-    ou, ov, ovalid, oscore, *_ = oracle.klt_track(img1, img2, pu[:n], pv[:n], threads=8)
-    assert (valid[:n] == ovalid).mean() > 0.998
-    both = valid[:n] & ovalid
+    ou, ov, ovalid, oscore, ofb, _ = oracle.klt_track(img1, img2, pu[:n], pv[:n], threads=8)
+    both = assert_validity(valid[:n], ovalid, ofb, 2.0, 1480)
     assert np.hypot(qu[:n] - ou, qv[:n] - ov)[both].max() < PX_TOL
     # idempotence of the frame cache: a second call on the same pair gives identical bits
     qu2, qv2, valid2, _ = klt_gpu(img1, img2, pu, pv, 4, 41, 41, 50, 2.0)
@@ -104,11 +115,10 @@ def test_klt_window_classes_and_borders(ctx, wu, wv, levels):
     img1, img2, _ = synth.frame_pair(nv=nv, nu=nu, seed=11, shift=(1.7, -1.2), zoom=0.003)
     pu, pv = synth.keypoints(400, nv=nv, nu=nu, seed=12, border=0.0)
     qu, qv, valid, score = klt_gpu(img1, img2, pu, pv, levels, wu, wv, 30, 1.5)
-    ou, ov, ovalid, oscore, *_ = oracle.klt_track(img1, img2, pu, pv, levels=levels, max_bidir=1.5, wu=wu, wv=wv,
-                                                  max_iters=30, threads=8)
-    assert (valid == ovalid).mean() >= 0.97
-    both = valid & ovalid
-    assert both.sum() > 100
+    ou, ov, ovalid, oscore, ofb, _ = oracle.klt_track(img1, img2, pu, pv, levels=levels, max_bidir=1.5, wu=wu, wv=wv,
+                                                      max_iters=30, threads=8)
+    both = assert_validity(valid, ovalid, ofb, 1.5, 370)
+    assert (~ovalid).sum() >= 5                           # points that leave the image or fail the check are in the set
     assert np.hypot(qu - ou, qv - ov)[both].max() < PX_TOL
     assert np.abs(score - oscore)[both].max() < 1e-3
 
@@ -119,11 +129,10 @@ def test_klt_images_smaller_than_the_patch(ctx, nv, nu):
     img1, img2, _ = synth.frame_pair(nv=nv, nu=nu, seed=13, shift=(0.8, 0.6), margin=16)
     pu, pv = synth.keypoints(64, nv=nv, nu=nu, seed=14, border=2.0)
     qu, qv, valid, score = klt_gpu(img1, img2, pu, pv, 3, 31, 31, 30, 2.0)
-    ou, ov, ovalid, oscore, *_ = oracle.klt_track(img1, img2, pu, pv, levels=3, max_bidir=2.0, wu=31, wv=31, max_iters=30)
-    assert (valid == ovalid).mean() >= 0.95
-    both = valid & ovalid
-    if both.any():
-        assert np.hypot(qu - ou, qv - ov)[both].max() < PX_TOL
+    ou, ov, ovalid, oscore, ofb, _ = oracle.klt_track(img1, img2, pu, pv, levels=3, max_bidir=2.0, wu=31, wv=31, max_iters=30)
+    both = assert_validity(valid, ovalid, ofb, 2.0, 60)
+    assert np.hypot(qu - ou, qv - ov)[both].max() < PX_TOL
+    assert np.abs(score - oscore)[both].max() < 1e-3
 
 
 def test_klt_points_outside_the_image_or_not_finite(ctx):
@@ -160,11 +169,10 @@ def test_klt_smallest_images(ctx, nv, nu):
     img1, img2, _ = synth.frame_pair(nv=nv, nu=nu, seed=19, shift=(0.4, 0.3), margin=8)
     pu, pv = synth.keypoints(40, nv=nv, nu=nu, seed=20, border=0.0)
     qu, qv, valid, score = klt_gpu(img1, img2, pu, pv, 3, 7, 7, 30, 2.0)
-    ou, ov, ovalid, oscore, *_ = oracle.klt_track(img1, img2, pu, pv, levels=3, max_bidir=2.0, wu=7, wv=7, max_iters=30)
-    assert (valid == ovalid).mean() >= 0.9
-    both = valid & ovalid
-    if both.any():
-        assert np.hypot(qu[both] - ou[both], qv[both] - ov[both]).max() < PX_TOL
+    ou, ov, ovalid, oscore, ofb, _ = oracle.klt_track(img1, img2, pu, pv, levels=3, max_bidir=2.0, wu=7, wv=7, max_iters=30)
+    both = assert_validity(valid, ovalid, ofb, 2.0, 20)
+    assert (~ovalid).sum() >= 5                           # and points the oracle rejects, rejected here too
+    assert np.hypot(qu[both] - ou[both], qv[both] - ov[both]).max() < PX_TOL
     with pytest.raises(Exception):
         ops.klt_track(img1[:7], img2[:7], np.ones((3, 2)))
     if min(nv, nu) == 8:
@@ -199,9 +207,9 @@ def test_klt_malaga_shapes(ctx, nv, nu, n):
     err = np.hypot(qu - tu, qv - tv)
     assert valid.mean() > 0.99 and np.percentile(err[valid], 99) < 0.1
     m = 300
-    ou, ov, ovalid, *_ = oracle.klt_track(img1, img2, pu[:m], pv[:m], threads=8)
-    both = valid[:m] & ovalid
-    assert (valid[:m] == ovalid).mean() > 0.99 and np.hypot(qu[:m] - ou, qv[:m] - ov)[both].max() < PX_TOL
+    ou, ov, ovalid, _, ofb, _ = oracle.klt_track(img1, img2, pu[:m], pv[:m], threads=8)
+    both = assert_validity(valid[:m], ovalid, ofb, 2.0, 295)
+    assert np.hypot(qu[:m] - ou, qv[:m] - ov)[both].max() < PX_TOL
 
 
 # ---------------------------------------------------------------- selection
@@ -303,7 +311,9 @@ def test_triangulation_pose_table_and_scale(ctx):
     with pytest.raises(Exception):
         ops.triangulate_candidates(xy0[:4], xy1[:4], uniq.reshape(-1, 4, 3)[:2], pose1, K)  # P != C without a table
     bad = ops.triangulate_candidates(xy0[:4], xy1[:4], uniq.reshape(-1, 4, 3), pose1, K, first_pose_idx=[1, 2, 99, 0])
-    assert list(bad[3]) == [True, True, False, False] or not bad[3][2:].any()              # bad indices are flagged
+    assert not bad[3][2:].any()                                    # indices outside the table (99, 0 in 1-based) are flagged invalid
+    _, _, _, ok2 = oracle.triangulate(xy0[:2], xy1[:2], uniq.reshape(-1, 4, 3)[:2], pose1, K)
+    np.testing.assert_array_equal(bad[3][:2], ok2)                 # the good ones beside them are what the oracle says
 
 
 def test_angle_cheirality_reprojection(ctx):
