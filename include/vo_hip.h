@@ -243,6 +243,17 @@ int vo_dev_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, co
 int vo_dev_p3p_ransac(vo_ctx* ctx, const double* d_xy, const double* d_X, int M, const double* d_K,
                       const vo_ransac_opts* opts, const int32_t* d_sample_idx,
                       const double* d_hyp_poses_in, void* d_out, uint8_t* d_inliers);
+/* vo_dev_p3p_ransac for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code under
+ * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same kernels, same
+ * results as vo_dev_p3p_ransac; the per-hypothesis work arrays (poses, counts, MSAC costs) live in a static device
+ * array of the library (2.2 MB, held on every GPU the library runs on until the process ends) instead of the ctx's
+ * grow-only buffer, and the call makes no hipMalloc / hipFree.  opts->num_hyp above VO_STATIC_MAX_HYP is refused
+ * with VO_ERR_UNSUPPORTED.  All calls on one GPU share the array: calls that overlap on one GPU (two contexts, two
+ * threads) race -- serialise them. */
+#define VO_STATIC_MAX_HYP 5120
+int vo_dev_p3p_ransac_static(vo_ctx* ctx, const double* d_xy, const double* d_X, int M, const double* d_K,
+                             const vo_ransac_opts* opts, const int32_t* d_sample_idx,
+                             const double* d_hyp_poses_in, void* d_out, uint8_t* d_inliers);
 
 /* ==== device-resident frame loop: VisualOdometry.processFrame,
  * modules/VisualOdometry.m:264-346, with the method candidateTriangulation (:63-151), the state kept

@@ -72,6 +72,10 @@ int vo_ctx_create(int device, vo_ctx** out) {
         return VO_ERR_HIP;
     }
     c->stream = c->own_stream;
+    if (vo_static_scratch_resolve(device) != VO_OK) {   // vo_dev_p3p_ransac_static's work array on this GPU
+        vo_ctx_destroy(c);
+        return VO_ERR_HIP;
+    }
     *out = c;
     return VO_OK;
 }

@@ -591,6 +591,63 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
 }
 
 
+// ================= allocation-free variant of vo_dev_p3p_ransac =================
+// For callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid
+// it): the per-hypothesis work arrays (poses, counts, MSAC costs) live in a file-scope device array instead of the
+// ctx's grow-only buffer.  Every GPU the library runs on holds its own copy of the array at its own address, until
+// the process ends; the address is looked up once per device (vo_static_scratch_resolve, called by vo_ctx_create
+// with that device current) and from then on only the looked-up pointer is used -- the array's NAME is a host-side
+// stand-in, not a device address.  All calls on one GPU share the array: calls that overlap on one GPU (two ctxs,
+// two threads) race.  Nothing in it has to start at zero: k_hyp / k_score write every entry k_best reads.
+namespace {
+constexpr size_t static_pad(size_t b) { return (b + 255) & ~(size_t)255; }
+constexpr size_t STATIC_RT = static_pad((size_t)VO_STATIC_MAX_HYP * 48 * sizeof(double));
+constexpr size_t STATIC_CNT = static_pad((size_t)VO_STATIC_MAX_HYP * 4 * sizeof(int32_t));
+constexpr size_t STATIC_COST = static_pad((size_t)VO_STATIC_MAX_HYP * 4 * sizeof(unsigned long long));
+constexpr size_t STATIC_BYTES = STATIC_RT + STATIC_CNT + STATIC_COST;   // 2.2 MB for 5120 hypotheses
+constexpr int STATIC_MAX_DEVICES = 64;
+}
+// (no __attribute__((used)) here: the host-side use below is what makes the compiler keep the array in the code
+// object AND give it a global symbol the runtime can look up; with the attribute it stays a local symbol and
+// hipGetSymbolAddress aborts)
+static __device__ __align__(256) unsigned char scratch[STATIC_BYTES];
+static unsigned char* g_scratch_ptr[STATIC_MAX_DEVICES];   // per device: where that GPU's copy of `scratch` lives
+
+int vo_static_scratch_resolve(int device) {
+    if (device < 0 || device >= STATIC_MAX_DEVICES) return VO_ERR_BAD_ARG;
+    if (g_scratch_ptr[device]) return VO_OK;
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return VO_ERR_HIP;   // the current device's copy
+    g_scratch_ptr[device] = (unsigned char*)p;
+    return VO_OK;
+}
+
+int vo_dev_p3p_ransac_static(vo_ctx* ctx, const double* d_xy, const double* d_X, int M, const double* d_K,
+                             const vo_ransac_opts* o, const int32_t* d_sample_idx, const double* d_hyp_poses_in,
+                             void* d_out, uint8_t* d_inliers) {
+    if (!ctx || !o || !d_xy || !d_X || !d_K || !d_out || !d_inliers) return VO_ERR_BAD_ARG;
+    if (o->num_hyp < 1) { ctx->last_error = "ransac: num_hyp < 1"; return VO_ERR_BAD_ARG; }
+    if (o->num_hyp > VO_STATIC_MAX_HYP) {
+        ctx->last_error = "vo_dev_p3p_ransac_static: num_hyp exceeds VO_STATIC_MAX_HYP (the static work array holds 5120 "
+                          "hypotheses); use vo_dev_p3p_ransac";
+        return VO_ERR_UNSUPPORTED;
+    }
+    if (ctx->device < 0 || ctx->device >= STATIC_MAX_DEVICES) { ctx->last_error = "vo_dev_p3p_ransac_static: device index beyond the table"; return VO_ERR_UNSUPPORTED; }
+    (void)hipSetDevice(ctx->device);
+    if (!g_scratch_ptr[ctx->device]) {   // vo_ctx_create resolves it; a ctx made before a reload of the table ends here
+        const int rc = vo_static_scratch_resolve(ctx->device);
+        if (rc) { ctx->last_error = "vo_dev_p3p_ransac_static: hipGetSymbolAddress failed"; return rc; }
+    }
+    unsigned char* base = g_scratch_ptr[ctx->device];   // never the array's name
+    vo_ransac_work w;
+    w.Rt = (double*)base;
+    w.cnt = (int32_t*)(base + STATIC_RT);
+    w.cost = (unsigned long long*)(base + STATIC_RT + STATIC_CNT);
+    vo_strides s2 = {2, 1}, s3 = {3, 1};
+    return vo_launch_ransac(ctx, d_xy, s2, d_X, s3, M, d_K, o, d_sample_idx, d_hyp_poses_in, &w, d_out, d_inliers);
+}
+
+
 // ================= essential-matrix MSAC (bootstrap, modules/bootstrap.m:76-79; oracle N10) =================
 namespace {
 
