@@ -103,6 +103,17 @@ void vo_ctx_destroy(vo_ctx* ctx);
 int vo_ctx_set_stream(vo_ctx* ctx, void* hip_stream);
 void* vo_ctx_get_stream(vo_ctx* ctx);
 int vo_ctx_sync(vo_ctx* ctx);
+/* A branch of a frame's dependency graph on a second, high-priority stream (the reference has no counterpart: MATLAB
+ * runs the steps of modules/VisualOdometry.m:264-346 one after the other, although the pose step :285-289 needs only
+ * the landmark tracks of :278 and the candidate tracking of :71 needs neither).  Between _begin and _end every
+ * vo_dev_* call of this ctx is enqueued on the lane stream, which starts behind everything enqueued on the ctx stream
+ * so far; after _end the calls go to the ctx stream again and run beside the lane; vo_ctx_lane_join makes the ctx
+ * stream wait for the lane's work (call it before the first consumer of the lane's results).  Scheduling only: the
+ * results are those of the same calls made in order on one stream.  Pyramids issued ahead (vo_dev_frame_prefetch)
+ * that both branches read: make the ctx stream wait for them first (vo_dev_frame_wait). */
+int vo_ctx_lane_begin(vo_ctx* ctx);
+int vo_ctx_lane_end(vo_ctx* ctx);
+int vo_ctx_lane_join(vo_ctx* ctx);
 const char* vo_ctx_last_error(vo_ctx* ctx);
 /* counters: [0] LK iterations executed (window passes), [1] keypoints tracked, [2] LK template
  * set-ups (level x direction x point), [3] hypotheses scored */
@@ -234,6 +245,8 @@ int vo_dev_select_finish(vo_ctx* ctx, int u_is_rows, const float* d_eu, const fl
  * the tracker and detectMinEigenFeatures one after the other, main.m:52-59). */
 int vo_dev_frame_prefetch(vo_ctx* ctx, int slot, const uint8_t* d_img, int nu, int nv, int levels,
                           const vo_sel_opts* opts, int max_exist);
+/* the ctx stream waits (once) for a pyramid that vo_dev_frame_prefetch is building into `slot` */
+int vo_dev_frame_wait(vo_ctx* ctx, int slot);
 /* row-major device arrays: xy C x 2, poses P x 12, X C x 3 */
 int vo_dev_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, const double* d_poses0,
                        int P, const int32_t* d_pose_idx, int C, const double* d_pose1,
@@ -246,7 +259,7 @@ int vo_dev_p3p_ransac(vo_ctx* ctx, const double* d_xy, const double* d_X, int M,
 /* vo_dev_p3p_ransac for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for code under
  * HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same arguments, same kernels, same
  * results as vo_dev_p3p_ransac; the per-hypothesis work arrays (poses, counts, MSAC costs) live in a static device
- * array of the library (2.2 MB, held on every GPU the library runs on until the process ends) instead of the ctx's
+ * array of the library (2.4 MB, held on every GPU the library runs on until the process ends) instead of the ctx's
  * grow-only buffer, and the call makes no hipMalloc / hipFree.  opts->num_hyp above VO_STATIC_MAX_HYP is refused
  * with VO_ERR_UNSUPPORTED.  All calls on one GPU share the array: calls that overlap on one GPU (two contexts, two
  * threads) race -- serialise them. */

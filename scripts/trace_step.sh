@@ -10,14 +10,16 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 lk = [i for i, r in enumerate(rows) if "k_lk" in r["Kernel_Name"]]
-i0, i1 = lk[-12], lk[-11]                      # one steady step: from one k_lk launch to the next
+i0, i1 = lk[-124], lk[-120] + 1                # inside the K timed steps (behind them come 90 roofline-leg launches): two steps
 t0 = int(rows[i0]["Start_Timestamp"])
 prev_end = None
 for r in rows[i0:i1 + 1]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[:28]
+    import re
+    m = re.search(r"(k_\w+|__amd_rocclr_\w+)", r["Kernel_Name"])
+    name = (m.group(1) if m else r["Kernel_Name"])[:28] + " g" + r.get("Grid_Size", r.get("Grid_Size_X", "?"))
     gap = "" if prev_end is None else "%7.1f" % ((s - prev_end) / 1e3)
-    print("%-28s start %8.1f us  dur %7.1f us  gap %s  q%s" % (name, (s - t0) / 1e3, (e - s) / 1e3, gap, r.get("Queue_Id", "?")))
+    print("%-36s start %8.1f us  dur %7.1f us  gap %s  q%s" % (name, (s - t0) / 1e3, (e - s) / 1e3, gap, r.get("Queue_Id", "?")))
     prev_end = max(prev_end or e, e)
 PY
 cat $O/timeline.txt

@@ -466,3 +466,26 @@ def test_ransac_adaptive_run_still_scores_everything_when_asked(ctx):
     np.testing.assert_array_equal(s["counts"], b["counts"])
     np.testing.assert_array_equal(s["costs"], b["costs"])
     assert s["trials"] == b["trials"] and s["best_hyp"] == b["best_hyp"]
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("confidence", [0.0, 0.99])
+def test_ransac_early_out_changes_no_result(ctx, mode, confidence):
+    """Runs of more than 512 hypotheses score the hypotheses behind the first 256 with an early out: a pose whose
+    cost (count) can no longer strictly beat the first stage's record is dropped from the remaining points (k_score,
+    ScoreArgs::bound).  Record, trial count, pose and inlier set must be those of the full scoring, which a caller
+    gets by asking for the per-hypothesis outputs (want_all)."""
+    for m, frac, hyp, seed, min_inl in ((25000, 0.2, 2000, 3, 4), (6000, 0.5, 1500, 4, 30), (9000, 0.05, 700, 5, 4),
+                                        (5000, 0.93, 900, 6, 4), (1500, 0.3, 3000, 7, 4)):
+        xy, X, *_ = synth.pnp_scene(m, seed=80 + seed, outlier_frac=frac)
+        kw = dict(num_hyp=hyp, max_reproj_err=2.0, confidence=confidence, seed=seed, mode=mode, min_inliers=min_inl)
+        full = ops.p3p_ransac(xy, X, K, want_all=True, **kw)
+        fast = ops.p3p_ransac(xy, X, K, **kw)
+        for key in ("status", "best_hyp", "best_sol", "trials", "num_inliers"):
+            assert fast[key] == full[key], (key, m, frac, hyp)
+        np.testing.assert_array_equal(fast["R"], full["R"]); np.testing.assert_array_equal(fast["t"], full["t"])
+        np.testing.assert_array_equal(fast["inliers"], full["inliers"])
+        # the hypotheses of the full run, scored by the fast path: still the same record
+        again = ops.p3p_ransac(xy, X, K, hyp_poses=full["poses"], **kw)
+        assert (again["best_hyp"], again["best_sol"], again["trials"]) == (full["best_hyp"], full["best_sol"], full["trials"])
+        np.testing.assert_array_equal(again["inliers"], full["inliers"])

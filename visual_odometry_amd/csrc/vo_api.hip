@@ -99,6 +99,12 @@ void vo_ctx_destroy(vo_ctx* c) {
         (void)hipStreamSynchronize(c->side);
         (void)hipStreamDestroy(c->side);
     }
+    if (c->lane) {
+        (void)hipStreamSynchronize(c->lane);
+        (void)hipStreamDestroy(c->lane);
+    }
+    if (c->ev_lane_fork) (void)hipEventDestroy(c->ev_lane_fork);
+    if (c->ev_lane_done) (void)hipEventDestroy(c->ev_lane_done);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->sel_pending)
@@ -110,6 +116,9 @@ void vo_ctx_destroy(vo_ctx* c) {
 
 int vo_ctx_set_stream(vo_ctx* ctx, void* s) {
     if (!ctx) return VO_ERR_BAD_ARG;
+    if (ctx->in_lane) { ctx->last_error = "vo_ctx_set_stream: inside vo_ctx_lane_begin / _end"; return VO_ERR_BAD_ARG; }
+    if (ctx->lane) VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane));
+    ctx->lane_pending = false;
     VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->side) VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->side));
     ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
@@ -120,6 +129,49 @@ int vo_ctx_sync(vo_ctx* ctx) {
     if (!ctx) return VO_ERR_BAD_ARG;
     VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->side) VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->side));   // work begun ahead (prefetch, detect half)
+    if (ctx->lane) VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane));   // a branch begun with vo_ctx_lane_begin
+    if (ctx->in_lane) VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane_saved));
+    return VO_OK;
+}
+
+// ---- lane: a branch of the frame's dependency graph on a second stream ----
+int vo_ctx_lane_begin(vo_ctx* ctx) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    if (ctx->in_lane) { ctx->last_error = "vo_ctx_lane_begin: a lane is already open"; return VO_ERR_BAD_ARG; }
+    (void)hipSetDevice(ctx->device);
+    if (!ctx->lane) {
+        int lo = 0, hi = 0;   // numerically lower = higher priority
+        VO_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        VO_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->lane, hipStreamNonBlocking, hi));
+        VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming));
+        VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_done, hipEventDisableTiming));
+    }
+    if (ctx->lane_pending) {   // an earlier branch nobody joined: the new one comes behind it anyway (same stream)
+        ctx->lane_pending = false;
+    }
+    VO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_lane_fork, ctx->stream));
+    VO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->lane, ctx->ev_lane_fork, 0));
+    ctx->lane_saved = ctx->stream;
+    ctx->stream = ctx->lane;
+    ctx->in_lane = true;
+    return VO_OK;
+}
+int vo_ctx_lane_end(vo_ctx* ctx) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    if (!ctx->in_lane) { ctx->last_error = "vo_ctx_lane_end: no lane is open"; return VO_ERR_BAD_ARG; }
+    ctx->stream = ctx->lane_saved;
+    ctx->in_lane = false;
+    VO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_lane_done, ctx->lane));
+    ctx->lane_pending = true;
+    return VO_OK;
+}
+int vo_ctx_lane_join(vo_ctx* ctx) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    if (ctx->in_lane) { ctx->last_error = "vo_ctx_lane_join: the lane is still open"; return VO_ERR_BAD_ARG; }
+    if (ctx->lane_pending) {
+        VO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_done, 0));
+        ctx->lane_pending = false;
+    }
     return VO_OK;
 }
 const char* vo_ctx_last_error(vo_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
@@ -215,6 +267,12 @@ static int frame_await(vo_ctx* ctx, vo_pyr* f) {
         f->ready_pending = false;
     }
     return VO_OK;
+}
+
+int vo_dev_frame_wait(vo_ctx* ctx, int slot) {
+    if (!ctx || slot < 0 || slot >= VO_NUM_FRAME_SLOTS) return VO_ERR_BAD_ARG;
+    if (!ctx->frames[slot].valid) { ctx->last_error = "vo_dev_frame_wait: frame slot not built"; return VO_ERR_BAD_ARG; }
+    return frame_await(ctx, &ctx->frames[slot]);
 }
 
 int vo_dev_frame_build(vo_ctx* ctx, int slot, const uint8_t* d_img, int nu, int nv, int levels) {

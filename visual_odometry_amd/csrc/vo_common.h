@@ -44,6 +44,11 @@ struct vo_ctx {
     // side stream for work that depends on the new image only (corner detection) and runs beside tracking
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // lane: a second, high-priority stream for a branch of the frame's dependency graph that runs beside the main
+    // one (landmark tracking -> pose, beside candidate tracking); vo_ctx_lane_begin / _end / _join
+    hipStream_t lane = nullptr, lane_saved = nullptr;
+    hipEvent_t ev_lane_fork = nullptr, ev_lane_done = nullptr;
+    bool in_lane = false, lane_pending = false;
     struct vo_sel_pending* sel_pending = nullptr;  // vo_dev_select_begin .. vo_dev_select_finish
     uint64_t sel_gen[2] = {0, 0};   // bumped whenever a selection work area is handed out: work issued ahead into it
                                     // (look-ahead, open selections) is valid only while the number stands
@@ -117,7 +122,12 @@ int vo_launch_reproj(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
                      const double* d_pose, int pose_col_major, const double* d_K, double* d_err,
                      const int32_t* d_n = nullptr);   // d_n: the count on the device (n is then its upper bound)
 
-struct vo_ransac_work { double* Rt; int32_t* cnt; unsigned long long* cost; };
+struct vo_ransac_work {
+    double* Rt; int32_t* cnt; unsigned long long* cost;
+    // cnt | cost | {bound[2], list_n} are one contiguous block of zero_bytes bytes, zeroed at the start of a run
+    // (k_score adds into cnt / cost); list: pose ids that survive the first quarter of the points (k_survivors)
+    unsigned long long* bound = nullptr; int32_t* list_n = nullptr; int32_t* list = nullptr; size_t zero_bytes = 0;
+};
 int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int M,
                      const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
                      const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers,

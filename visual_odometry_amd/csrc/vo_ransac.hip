@@ -6,10 +6,13 @@
 //
 //   k_hyp      one thread per hypothesis: sample 3 indices (seeded Philox4x32-10 or a caller table),
 //              bearings, P3P -> 4 x (R_cw, t_cw)
-//   k_score    one 256-thread block per SC_HB hypotheses: every thread walks the points once and
-//              scores 4*SC_HB poses per point from LDS-broadcast pose rows; inlier counts and MSAC
-//              costs are integers, reduced across the wavefront by DPP/shuffle and across the four
-//              waves through LDS -- order independent, hence bit-exact
+//   k_score    one 256-thread block per 8 poses (SC_HB hypotheses, or 8 ids of the survivor list) and part of
+//              the points: every thread walks its points once and scores the 8 poses per point from
+//              LDS-broadcast pose rows; inlier counts and MSAC costs are integers, reduced across the
+//              wavefront by shuffles, across the four waves through LDS and across blocks / launches by
+//              atomic adds -- order independent, hence bit-exact
+//   k_survivors  long runs: the poses that can still beat the first 256 hypotheses' record after a quarter
+//              of the points; only they see the other three quarters
 //   k_best     one wavefront: sequential RANSAC semantics (strict-improvement updates, adaptive
 //              stop) evaluated as a chunked prefix scan
 //   k_inliers  inlier mask of the winning pose
@@ -225,7 +228,13 @@ struct HypArgs {
     const int32_t* M_dev;   // non-null: the point count lives on the device, M is only its upper bound
 };
 
-__global__ __launch_bounds__(64) void k_hyp(HypArgs a) {
+// The pose chain may run on the ctx's lane stream beside a tracking launch that fills every SIMD (vo_ctx_lane_*):
+// its waves then arbitrate for issue slots against older tracking waves and, being the younger ones, lose (k_hyp:
+// 12 us alone, 240 us beside k_lk).  A raised wave priority lets these short kernels through.
+#define VO_POSE_PRIO() __builtin_amdgcn_s_setprio(3)
+
+__global__ __launch_bounds__(64, 4) void k_hyp(HypArgs a) {   // <= 128 VGPRs: fits the hole one finished tracking wave leaves (160 did not: the kernel starved beside k_lk)
+    VO_POSE_PRIO();
     const int h = a.h0 + blockIdx.x * 64 + threadIdx.x;
     if (h >= a.H || (a.stopped && *a.stopped)) return;
     if (a.M_dev) { a.M = min(a.M, *a.M_dev); if (a.M < 4) return; }
@@ -290,40 +299,59 @@ struct ScoreArgs {
     const double* xy; vo_strides sxy; const double* X; vo_strides sX; int M;
     const double* K; int H; double thr2; const double* Rt; int32_t* cnt; unsigned long long* cost;
     unsigned long long* counters;
-    int h0;                 // first hypothesis of this launch
+    int h0;                 // contiguous form: first hypothesis of this launch (block b scores hypotheses h0 + 2b, h0 + 2b + 1)
+    const int32_t* list;    // list form (non-null): pose ids 4h + s, eight per block, *list_n of them
+    const int32_t* list_n;
+    int q0, q1;             // the launch scores points [M q0 / 8, M q1 / 8); blockIdx.y takes one of gridDim.y equal parts
     const int32_t* stopped; // as in HypArgs
     const int32_t* M_dev;   // as in HypArgs
 };
 
+// Scores 8 poses per block on a range of the points and ADDS what it finds to cnt / cost (zeroed by the launcher):
+// the inlier count, and the MSAC cost of the range = inlier terms + (points of the range - inliers) * qthr.  All
+// sums are integers, so any split of the points over blocks and launches gives the same totals.
 __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
+    VO_POSE_PRIO();
     __shared__ double sRt[SC_NS * 12];
+    __shared__ int s_pid[SC_NS];
     __shared__ int s_cnt[4][SC_NS];
     __shared__ unsigned long long s_cost[4][SC_NS];
     if (a.stopped && *a.stopped) return;   // uniform: the whole launch has nothing to do
     if (a.M_dev) { a.M = min(a.M, *a.M_dev); if (a.M < 4) return; }
-    const int h0 = a.h0 + blockIdx.x * SC_HB;
     const int tid = threadIdx.x;
-    if (tid < SC_NS * 12) {
-        const int hs = tid / 12;             // pose within the block
-        const int h = h0 + hs / 4;
-        const int e = tid - 12 * hs;         // element of the pose's 3x4 projection
-        sRt[tid] = h < a.H ? proj_elem(a.Rt + 48 * (long)h0 + 12 * hs, a.K, e >> 2, e & 3) : 0.0;
+    const int nlist = a.list ? *a.list_n : 0;
+    if (a.list && (int)blockIdx.x * SC_NS >= nlist) return;   // uniform
+    if (tid < SC_NS) {
+        int pid;
+        if (a.list) { const int k = blockIdx.x * SC_NS + tid; pid = k < nlist ? a.list[k] : -1; }
+        else { pid = 4 * a.h0 + (int)blockIdx.x * SC_NS + tid; if (pid >= 4 * a.H) pid = -1; }
+        s_pid[tid] = pid;
     }
     __syncthreads();
+    if (tid < SC_NS * 12) {
+        const int hs = tid / 12;             // pose within the block
+        const int e = tid - 12 * hs;         // element of the pose's 3x4 projection
+        const int pid = s_pid[hs];
+        sRt[tid] = pid >= 0 ? proj_elem(a.Rt + 12 * (long)pid, a.K, e >> 2, e & 3) : 0.0;
+    }
+    __syncthreads();
+    const long r0 = (long)a.M * a.q0 / 8, r1 = (long)a.M * a.q1 / 8;
+    const long per = (r1 - r0 + gridDim.y - 1) / gridDim.y;
+    const int c0 = (int)(r0 + per * blockIdx.y), c1 = (int)min(r0 + per * (blockIdx.y + 1), r1);
     const double thr2 = a.thr2;
     const unsigned long long qthr = (unsigned long long)(thr2 * 1048576.0);
     int cnt[SC_NS];
-    unsigned long long cost[SC_NS]; // inlier terms only; the outliers' (M - cnt) * qthr is added at the end
+    unsigned long long cost[SC_NS]; // inlier terms only; the outliers' (points - cnt) * qthr is added at the end
 #pragma unroll
     for (int s = 0; s < SC_NS; ++s) { cnt[s] = 0; cost[s] = 0; }
     // SC_PT points per thread and pass: a pose read from LDS serves all of them
-    for (int i0 = tid; i0 < a.M; i0 += 256 * SC_PT) {
+    for (int i0 = c0 + tid; i0 < c1; i0 += 256 * SC_PT) {
         double X0[SC_PT], X1[SC_PT], X2[SC_PT], u[SC_PT], v[SC_PT];
         bool has[SC_PT];
 #pragma unroll
         for (int p = 0; p < SC_PT; ++p) {
             const int i = i0 + 256 * p;
-            has[p] = i < a.M;
+            has[p] = i < c1;
             const int j = has[p] ? i : i0;
             X0[p] = a.X[j * a.sX.xi]; X1[p] = a.X[j * a.sX.xi + a.sX.xc]; X2[p] = a.X[j * a.sX.xi + 2 * a.sX.xc];
             u[p] = a.xy[j * a.sxy.xi]; v[p] = a.xy[j * a.sxy.xi + a.sxy.xc];
@@ -362,16 +390,42 @@ __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
         if (lane == 0) { s_cnt[wid][s] = c; s_cost[wid][s] = q; }
     }
     __syncthreads();
-    if (tid < SC_NS) {
-        const int h = h0 + tid / 4;
-        if (h < a.H) {
-            const int c = (s_cnt[0][tid] + s_cnt[1][tid]) + (s_cnt[2][tid] + s_cnt[3][tid]);
-            a.cnt[4 * (long)h0 + tid] = c;
-            a.cost[4 * (long)h0 + tid] = (s_cost[0][tid] + s_cost[1][tid]) + (s_cost[2][tid] + s_cost[3][tid]) +
-                                         (unsigned long long)(a.M - c) * qthr;
-        }
+    if (tid < SC_NS && s_pid[tid] >= 0 && c1 > c0) {
+        const int c = (s_cnt[0][tid] + s_cnt[1][tid]) + (s_cnt[2][tid] + s_cnt[3][tid]);
+        const unsigned long long q = (s_cost[0][tid] + s_cost[1][tid]) + (s_cost[2][tid] + s_cost[3][tid]) +
+                                     (unsigned long long)((c1 - c0) - c) * qthr;
+        if (c) atomicAdd(&a.cnt[s_pid[tid]], c);
+        atomicAdd(&a.cost[s_pid[tid]], q);
     }
-    if (tid == 0 && a.counters) atomicAdd(&a.counters[4 * (blockIdx.x & (VO_COUNTER_SHARDS - 1)) + 3], (unsigned long long)min(SC_HB, a.H - h0));
+    if (tid == 0 && a.counters && !a.list && blockIdx.y == 0)
+        atomicAdd(&a.counters[4 * (blockIdx.x & (VO_COUNTER_SHARDS - 1)) + 3], (unsigned long long)min(SC_HB, a.H - (a.h0 + (int)blockIdx.x * SC_HB)));
+}
+
+// Which poses of the hypotheses [h0, H) can still become the record after `seen` eighths of the points?
+// bound[0] = the cost (mode 1) or the inlier count (mode 0) of the best record among the hypotheses BEFORE h0, written
+// by the first stage's k_best.  After n points a pose's final cost is at least its cost so far, its final count at most
+// its count so far + (M - n).  A later hypothesis replaces the record only by strict improvement
+// (old/ransacLocalization.m:107), and every hypothesis behind the bound is earlier in the order, so a pose that
+// cannot strictly improve on the bound could never have become the record: it is left out of the remaining points.
+// Record, trial count, pose and inlier set are those of the full scoring; only the per-hypothesis counts / costs of
+// the poses left out stay partial sums (callers who read them get the full scoring: score_all).
+// Candidates: every pose of [h0, H) (in == nullptr) or the previous round's list.
+struct SurvArgs {
+    const int32_t* cnt; const unsigned long long* cost; const unsigned long long* bound; int h0, H, M, mode, seen;
+    const int32_t* in; const int32_t* in_n; int32_t* list; int32_t* list_n; const int32_t* stopped; const int32_t* M_dev;
+};
+__global__ __launch_bounds__(256) void k_survivors(SurvArgs a) {
+    if (a.stopped && *a.stopped) return;
+    if (a.M_dev) { a.M = min(a.M, *a.M_dev); if (a.M < 4) return; }
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    int pid;
+    if (a.in) { if (k >= *a.in_n) return; pid = a.in[k]; }
+    else { pid = 4 * a.h0 + k; if (pid >= 4 * a.H) return; }
+    const unsigned long long bound = a.bound[0];
+    const long seen = (long)a.M * a.seen / 8;      // where k_score's ranges so far end
+    const bool alive = a.mode == 1 ? (a.cost[pid] < bound)
+                                   : ((unsigned long long)((long)a.cnt[pid] + ((long)a.M - seen)) > bound);
+    if (alive) a.list[atomicAdd(a.list_n, 1)] = pid;
 }
 
 // ---- sequential RANSAC semantics (old/ransacLocalization.m:86-124) as a chunked scan, one block ----
@@ -411,6 +465,7 @@ struct BestArgs {
     int sample_size;                // 3 (P3P) or 8 (eight-point)
     int later_stage;                // 1: an earlier stage ran on a prefix; keep its record if it reached the stop
     const int32_t* M_dev;           // as in HypArgs; fewer than 4 points: status 1 and the identity
+    unsigned long long* bound_out;  // non-null (first stage): the record's cost / count for k_score's early out
 };
 
 __device__ __forceinline__ BState combine(int mode, int min_inl, const BState& earlier, const BState& later) {
@@ -430,6 +485,7 @@ __device__ __forceinline__ BState shfl_up_state(const BState& x, int d) {
 constexpr int BEST_NT = 256;   // 1024 and 64 were measured too: 8 and 6 us slower per 2000-hypothesis launch
 constexpr int RANSAC_STAGE = 256;  // hypotheses of the first stage of an adaptive run (a multiple of 64 and of SC_HB)
 __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
+    VO_POSE_PRIO();
     __shared__ BState s_wave[BEST_NT / 64];
     __shared__ int s_stop;
     __shared__ BState s_fin;
@@ -506,6 +562,8 @@ __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
             info[0] = 2;
         }
         info[1] = fin.h; info[2] = fin.s; info[3] = used; info[4] = 0;
+        if (a.bound_out)   // no record yet: a bound no pose can fail
+            a.bound_out[0] = fin.h >= 0 ? (a.mode == 1 ? fin.q : (unsigned long long)fin.c) : (a.mode == 1 ? ~0ull : 0ull);
         info[5] = gstop == 0x7fffffff ? 0 : 1;   // the adaptive stop was reached inside these H hypotheses
     }
 }
@@ -517,6 +575,7 @@ struct InlArgs {
     double* pose_out;       // optional: the pose [R_WC; t_WC] of the record (modules/VisualOdometry.m:318), C = -R_cw^T t_cw
 };
 __global__ __launch_bounds__(256) void k_inliers(InlArgs a) {
+    VO_POSE_PRIO();
     const int i = blockIdx.x * 256 + threadIdx.x;
     int32_t* info = (int32_t*)(a.out + 12);
     if (i == 0 && a.pose_out) {
@@ -550,6 +609,13 @@ __global__ __launch_bounds__(64) void k_p3p_batch(const double* P, const double*
 
 } // namespace
 
+static int score_chunks(int nblocks, int npoints) {
+    // split the points over blockIdx.y when there are few hypotheses, so that a short launch still fills the chip
+    int c = 1;
+    while (c < 8 && nblocks * c < 768 && npoints / (2 * c) >= 2048) c *= 2;
+    return c;
+}
+
 int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int M,
                      const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,
                      const double* d_poses_in, vo_ransac_work* w, void* d_out, uint8_t* d_inliers, const int32_t* d_M, int score_all,
@@ -559,28 +625,66 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
     if (o->mode != 0 && o->mode != 1) { ctx->last_error = "ransac: mode must be 0 or 1"; return VO_ERR_BAD_ARG; }
     const double thr2 = o->max_reproj_err * o->max_reproj_err;
     const double* Rt = d_poses_in ? d_poses_in : w->Rt;
-    // With the adaptive stop (confidence > 0) the sequential semantics usually end after a few trials, and
-    // the record at the stop depends on the hypotheses before it only.  So a first stage generates, scores
-    // and scans the first RANSAC_STAGE hypotheses; the second stage (the rest, then the scan over all H)
-    // returns at once when the first one reached the stop.  Same result as one stage over all H.
+    // Two stages when the run is long.  The first generates, fully scores and scans the first RANSAC_STAGE hypotheses.
+    // With the adaptive stop (confidence > 0) the sequential semantics usually end among them -- the record at the
+    // stop depends on the hypotheses before it only -- and the second stage returns at once.  Otherwise the second
+    // stage scores the rest on the first 3/8 of the points, leaves out the poses that can no longer beat the first
+    // stage's record (k_survivors), scores the survivors on the next 3/8, sieves again, scores what is left on the
+    // last quarter, and scans all H.  Same record, trial count and inlier set as one stage over everything.
+    // score_all: the caller reads every hypothesis' counts -- one stage, nothing left out.
     const int32_t* stopped = (const int32_t*)((const double*)d_out + 12) + 5;
-    const bool staged = o->confidence > 0 && H > 2 * RANSAC_STAGE && !score_all;   // score_all: the caller reads every hypothesis' counts
-    for (int stage = 0; stage < (staged ? 2 : 1); ++stage) {
-        const int h0 = stage == 0 ? 0 : RANSAC_STAGE, h1 = (staged && stage == 0) ? RANSAC_STAGE : H;
-        if (!d_poses_in) {
-            HypArgs h;
-            h.xy = d_xy; h.sxy = sxy; h.X = d_X; h.sX = sX; h.M = M; h.K = d_K; h.H = h1; h.seed = o->seed;
-            h.sample_idx = d_sample_idx; h.Rt = w->Rt; h.h0 = h0; h.stopped = stage ? stopped : nullptr; h.M_dev = d_M;
-            hipLaunchKernelGGL(k_hyp, dim3((h1 - h0 + 63) / 64), dim3(64), 0, ctx->stream, h);
-        }
+    const bool staged = H > 2 * RANSAC_STAGE && !score_all && w->bound && w->list && M >= 4096;
+    // without a confidence nothing can end the run early: a short first stage is enough to set the bound, and all
+    // hypotheses are generated in one launch
+    const int S = o->confidence > 0 ? RANSAC_STAGE : RANSAC_STAGE / 4;
+    VO_HIP_CHECK(ctx, hipMemsetAsync(w->cnt, 0, w->zero_bytes, ctx->stream));   // counts, costs, bound, list length
+    auto hyp = [&](int h0, int h1, bool later) {
+        if (d_poses_in) return;
+        HypArgs h;
+        h.xy = d_xy; h.sxy = sxy; h.X = d_X; h.sX = sX; h.M = M; h.K = d_K; h.H = h1; h.seed = o->seed;
+        h.sample_idx = d_sample_idx; h.Rt = w->Rt; h.h0 = h0; h.stopped = later ? stopped : nullptr; h.M_dev = d_M;
+        hipLaunchKernelGGL(k_hyp, dim3((h1 - h0 + 63) / 64), dim3(64), 0, ctx->stream, h);
+    };
+    auto score = [&](int h0, int h1, int q0, int q1, bool later, int from_list) {   // from_list: 0 no, 1 / 2 which list
         ScoreArgs s;
         s.xy = d_xy; s.sxy = sxy; s.X = d_X; s.sX = sX; s.M = M; s.K = d_K; s.H = h1; s.thr2 = thr2; s.Rt = Rt;
-        s.cnt = w->cnt; s.cost = w->cost; s.counters = ctx->d_counters; s.h0 = h0; s.stopped = stage ? stopped : nullptr; s.M_dev = d_M;
-        hipLaunchKernelGGL(k_score, dim3((h1 - h0 + SC_HB - 1) / SC_HB), dim3(256), 0, ctx->stream, s);
+        s.cnt = w->cnt; s.cost = w->cost; s.counters = ctx->d_counters; s.h0 = h0; s.stopped = later ? stopped : nullptr; s.M_dev = d_M;
+        s.list = from_list == 0 ? nullptr : (from_list == 1 ? w->list : w->list + 4 * (size_t)H);
+        s.list_n = w->list_n + (from_list == 2 ? 1 : 0); s.q0 = q0; s.q1 = q1;
+        const int nb = (h1 - h0 + SC_HB - 1) / SC_HB;
+        // survivor launches: few blocks do anything (how few is known on the device only), so each takes a short
+        // piece of the range -- the launch is as long as one block
+        const int npts = (int)((long)M * (q1 - q0) / 8);
+        const int chunks = from_list ? (npts >= 8 * 512 ? 8 : 1) : score_chunks(nb, npts);
+        hipLaunchKernelGGL(k_score, dim3(nb, chunks), dim3(256), 0, ctx->stream, s);
+    };
+    auto best = [&](int h1, int later, bool write_bound) {
         BestArgs b;
         b.cnt = w->cnt; b.cost = w->cost; b.Rt = Rt; b.H = h1; b.M = M; b.mode = o->mode; b.min_inl = o->min_inliers;
-        b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 3; b.later_stage = stage; b.M_dev = d_M;
+        b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 3; b.later_stage = later; b.M_dev = d_M;
+        b.bound_out = write_bound ? w->bound : nullptr;
         hipLaunchKernelGGL(k_best, dim3(1), dim3(BEST_NT), 0, ctx->stream, b);
+    };
+    if (!staged) {
+        hyp(0, H, false);
+        score(0, H, 0, 8, false, 0);
+        best(H, 0, false);
+    } else {
+        hyp(0, o->confidence > 0 ? S : H, false);
+        score(0, S, 0, 8, false, 0);
+        best(S, 0, true);
+        if (o->confidence > 0) hyp(S, H, true);
+        score(S, H, 0, 3, true, 0);                     // the first 3/8 of the points
+        SurvArgs sv;
+        sv.cnt = w->cnt; sv.cost = w->cost; sv.bound = w->bound; sv.h0 = S; sv.H = H; sv.M = M; sv.mode = o->mode;
+        sv.stopped = stopped; sv.M_dev = d_M;
+        sv.seen = 3; sv.in = nullptr; sv.in_n = nullptr; sv.list = w->list; sv.list_n = w->list_n;
+        hipLaunchKernelGGL(k_survivors, dim3((4 * (H - S) + 255) / 256), dim3(256), 0, ctx->stream, sv);
+        score(S, H, 3, 6, true, 1);                     // the survivors on the next 3/8
+        sv.seen = 6; sv.in = w->list; sv.in_n = w->list_n; sv.list = w->list + 4 * (size_t)H; sv.list_n = w->list_n + 1;
+        hipLaunchKernelGGL(k_survivors, dim3((4 * (H - S) + 255) / 256), dim3(256), 0, ctx->stream, sv);
+        score(S, H, 6, 8, true, 2);                     // what is left on the last quarter
+        best(H, 1, false);
     }
     InlArgs in;
     in.xy = d_xy; in.sxy = sxy; in.X = d_X; in.sX = sX; in.M = M; in.K = d_K; in.thr2 = thr2; in.out = (double*)d_out;
@@ -598,13 +702,15 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
 // the process ends; the address is looked up once per device (vo_static_scratch_resolve, called by vo_ctx_create
 // with that device current) and from then on only the looked-up pointer is used -- the array's NAME is a host-side
 // stand-in, not a device address.  All calls on one GPU share the array: calls that overlap on one GPU (two ctxs,
-// two threads) race.  Nothing in it has to start at zero: k_hyp / k_score write every entry k_best reads.
+// two threads) race.  The launcher zeroes what must start at zero (counts, costs, the survivor count) with one
+// hipMemsetAsync on the looked-up pointer at the start of every run.
 namespace {
 constexpr size_t static_pad(size_t b) { return (b + 255) & ~(size_t)255; }
 constexpr size_t STATIC_RT = static_pad((size_t)VO_STATIC_MAX_HYP * 48 * sizeof(double));
 constexpr size_t STATIC_CNT = static_pad((size_t)VO_STATIC_MAX_HYP * 4 * sizeof(int32_t));
 constexpr size_t STATIC_COST = static_pad((size_t)VO_STATIC_MAX_HYP * 4 * sizeof(unsigned long long));
-constexpr size_t STATIC_BYTES = STATIC_RT + STATIC_CNT + STATIC_COST;   // 2.2 MB for 5120 hypotheses
+constexpr size_t STATIC_LIST = static_pad((size_t)VO_STATIC_MAX_HYP * 8 * sizeof(int32_t));   // two survivor lists
+constexpr size_t STATIC_BYTES = STATIC_RT + STATIC_CNT + STATIC_COST + 256 + STATIC_LIST;   // 2.4 MB for 5120 hypotheses
 constexpr int STATIC_MAX_DEVICES = 64;
 }
 // (no __attribute__((used)) here: the host-side use below is what makes the compiler keep the array in the code
@@ -643,6 +749,10 @@ int vo_dev_p3p_ransac_static(vo_ctx* ctx, const double* d_xy, const double* d_X,
     w.Rt = (double*)base;
     w.cnt = (int32_t*)(base + STATIC_RT);
     w.cost = (unsigned long long*)(base + STATIC_RT + STATIC_CNT);
+    w.bound = (unsigned long long*)(base + STATIC_RT + STATIC_CNT + STATIC_COST);
+    w.list_n = (int32_t*)(w.bound + 2);
+    w.zero_bytes = STATIC_CNT + STATIC_COST + 256;
+    w.list = (int32_t*)(base + STATIC_RT + STATIC_CNT + STATIC_COST + 256);
     vo_strides s2 = {2, 1}, s3 = {3, 1};
     return vo_launch_ransac(ctx, d_xy, s2, d_X, s3, M, d_K, o, d_sample_idx, d_hyp_poses_in, &w, d_out, d_inliers);
 }
@@ -893,6 +1003,7 @@ int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_
                                            hipMemcpyDeviceToDevice, ctx->stream));
     }
     BestArgs b;
+    b.bound_out = nullptr;
     b.cnt = w->cnt; b.cost = w->cost; b.Rt = w->Rt; b.H = H; b.M = M; b.mode = 1; b.min_inl = o->min_inliers;
     b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 8; b.later_stage = 0; b.M_dev = nullptr;
     hipLaunchKernelGGL(k_best, dim3(1), dim3(BEST_NT), 0, ctx->stream, b);

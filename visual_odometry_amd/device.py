@@ -27,6 +27,10 @@ class FrameWorkload:
         stream (vo_dev_frame_prefetch); None: on unless VO_NO_PREFETCH is set (A/B switch for profiling)."""
         self.ctx = ctx
         self.ahead = (not os.environ.get("VO_NO_PREFETCH")) if ahead is None else bool(ahead)
+        # branch-parallel schedule: landmark tracking -> pose on the ctx's lane stream beside candidate tracking
+        # (modules/VisualOdometry.m: the pose step :285-289 needs the landmark tracks of :278 only, the candidate
+        # tracking of :71 neither).  VO_NO_LANE=1: one tracking launch over both sets, then the pose (A/B switch).
+        self.lane = not os.environ.get("VO_NO_LANE")
         self.dev = torch.device("cuda", ctx.device if device is None else device)
         self.nu, self.nv, self.levels, self.block = nu, nv, levels, block
         self.max_iters, self.eps, self.max_bidir = max_iters, eps, max_bidir
@@ -135,16 +139,27 @@ class FrameWorkload:
         k, n = self.k, self.n_frames
         a = 3 if k % n == 0 else (k - 1) % 3
         b = k % 3
-        if lap:
-            self.ctx.lap_begin()
-        self.track_all(a, b)
-        if lap:
-            self.ctx.lap_end()
+        branch = self.lane and not lap and self.nl >= 4
+        if branch:
+            self.ctx.call("vo_dev_frame_wait", a); self.ctx.call("vo_dev_frame_wait", b)
+            self.ctx.call("vo_ctx_lane_begin")
+            self.track_landmarks(a, b)
+            self.pose()
+            self.ctx.call("vo_ctx_lane_end")
+            self.track_candidates(a, b)
+        else:
+            if lap:
+                self.ctx.lap_begin()
+            self.track_all(a, b)
+            if lap:
+                self.ctx.lap_end()
         k1 = k + 1                       # the step after this one: its new frame, and frame 0 again if it wraps
         self.prefetch(k1 % 3, (k1 % n) + 1)
         if k1 % n == 0:
             self.prefetch(3, 0, select=False)
-        if self.nl >= 4:
+        if branch:
+            self.ctx.call("vo_ctx_lane_join")
+        elif self.nl >= 4:
             self.pose()
         self.triangulate()
         self.select_finish()             # the selection on this step's new frame, begun one step ago
