@@ -245,7 +245,7 @@ static int frame_prepare(vo_ctx* ctx, vo_pyr* f, int nu, int nv, int levels) {
     int a = nu, b = nv;
     for (int l = 0; l < levels; ++l) {
         f->nus[l] = a; f->nvs[l] = b; f->offs[l] = tot;
-        tot += (long)a * b;
+        tot += (long)(a + 2 * VO_PYR_PAD) * (b + 2 * VO_PYR_PAD);
         a = (a + 1) / 2; b = (b + 1) / 2;
     }
     if (f->nus[levels - 1] < 2 || f->nvs[levels - 1] < 2) { ctx->last_error = "frame: too many pyramid levels for this image"; return VO_ERR_BAD_ARG; }

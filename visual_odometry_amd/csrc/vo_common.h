@@ -8,6 +8,11 @@
 #include "../../include/vo_hip.h"
 
 #define VO_MAX_LEVELS 8
+// Every pyramid level is stored with a replicated border of VO_PYR_PAD pixels on each side (pitch = nu + 2 PAD):
+// a tracking patch around any position inside the image then lies inside the stored plane, so the tracker stages it
+// with unclamped 16-byte rows instead of per-lane row / column clamps (vo_klt.hip stage()).  offs[l] is the start of
+// level l's padded plane; pixel (u, v) of the level sits at offs[l] + (v + PAD) * (nus[l] + 2 PAD) + u + PAD.
+#define VO_PYR_PAD 32
 #define VO_MIN_EIG 1e-3
 
 #define VO_COUNTER_SHARDS 256 // counters are sharded by keypoint / block index to avoid one hot word

@@ -122,10 +122,18 @@ __device__ __forceinline__ float and_bits(float x, int m) { return __int_as_floa
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-// pyramid geometry of level l (wave-uniform scalar arithmetic; same rule as frame_prepare)
-__device__ __forceinline__ void level_dims(int nu0, int nv0, int l, int& nu, int& nv, long& off) {
-    nu = nu0; nv = nv0; off = 0;
-    for (int k = 0; k < l; ++k) { off += (long)nu * nv; nu = (nu + 1) >> 1; nv = (nv + 1) >> 1; }
+// pyramid geometry of level l (wave-uniform scalar arithmetic; same rule as frame_prepare): every level is stored
+// with a replicated border of VO_PYR_PAD pixels (vo_common.h); org = offset of the level's pixel (0, 0)
+constexpr int PYR_PAD = VO_PYR_PAD;
+__device__ __forceinline__ void level_dims(int nu0, int nv0, int l, int& nu, int& nv, long& org, int& pitch) {
+    nu = nu0; nv = nv0;
+    long off = 0;
+    for (int k = 0; k < l; ++k) {
+        off += (long)(nu + 2 * PYR_PAD) * (nv + 2 * PYR_PAD);
+        nu = (nu + 1) >> 1; nv = (nv + 1) >> 1;
+    }
+    pitch = nu + 2 * PYR_PAD;
+    org = off + (long)PYR_PAD * pitch + PYR_PAD;
 }
 
 // Stage the whole PW x PH patch (replicate-clamped coordinates): every LDS word a lane can read
@@ -136,7 +144,7 @@ typedef __attribute__((address_space(3))) float lds_float;
 typedef __attribute__((address_space(1))) const float glb_float;
 
 template <class C>
-__device__ __forceinline__ void stage(float* patch, const float* __restrict__ img, int nu, int nv, int ou, int ov,
+__device__ __forceinline__ void stage(float* patch, const float* __restrict__ img, int pitch, int nu, int nv, int ou, int ov,
                                       int lane, int lr, int lq) {
 #if defined(__HIP_DEVICE_COMPILE__) // the host pass cannot type-check the 16-byte LDS-DMA builtin
     __syncthreads();
@@ -147,42 +155,33 @@ __device__ __forceinline__ void stage(float* patch, const float* __restrict__ im
     constexpr int FAR = 1 << 24;
     ou = clampi(ou, -FAR, FAR);
     ov = clampi(ov, -FAR, FAR);
-    if (ou >= 0 && ou + C::PW <= nu) {
-        // Columns inside the image (wave-uniform): 16-byte LDS-DMA.  The LDS image is lane-linear per
-        // instruction (base + lane * 16), so with PW a multiple of 4 lanes (lr, lq) = (lane / NQ, lane % NQ)
-        // fill RPI whole rows per instruction from per-lane source addresses that need only 4-byte
-        // alignment (scripts/ubench/glds16.hip).  Rows are replicate-clamped per lane.
+    if (ou >= -PYR_PAD && ou + C::PW <= nu + PYR_PAD && ov >= -PYR_PAD && ov + C::PH <= nv + PYR_PAD) {
+        // The patch lies inside the stored plane (image + replicated border; wave-uniform test, true for every
+        // patch around a position inside the image unless the window is wider than 2 PAD - 7): 16-byte LDS-DMA
+        // with nothing clamped.  The LDS image is lane-linear per instruction (base + lane * 16), so with PW a
+        // multiple of 4 lanes (lr, lq) = (lane / NQ, lane % NQ) fill RPI whole rows per instruction from per-lane
+        // source addresses that need only 4-byte alignment (scripts/ubench/glds16.hip); the address just advances.
         constexpr int NQ = C::NQ, RPI = C::RPI, NI = (C::PH + RPI - 1) / RPI;
         if (lane < RPI * NQ) {
-            if (ov >= 0 && ov + C::PH <= nv) { // rows inside too: the per-lane address just advances
-                const float* g = img + ((long)(ov + lr) * nu + (ou + 4 * lq));
+            const float* g = img + ((long)(ov + lr) * pitch + (ou + 4 * lq));
 #pragma unroll
-                for (int k = 0; k < NI; ++k) {
-                    if ((k + 1) * RPI <= C::PH || lr < C::PH - k * RPI)
-                        __builtin_amdgcn_global_load_lds((glb_float*)g, lp + k * RPI * C::PW, 16, 0, 0);
-                    g += RPI * nu;
-                }
-            } else {
-                const unsigned col = (unsigned)(ou + 4 * lq); // a level has fewer than 2^24 rows / columns
-#pragma unroll
-                for (int k = 0; k < NI; ++k) {
-                    const unsigned row = (unsigned)clampi(ov + lr + k * RPI, 0, nv - 1);
-                    const unsigned off = __umul24(row, (unsigned)nu) + col;
-                    if ((k + 1) * RPI <= C::PH || lr < C::PH - k * RPI)
-                        __builtin_amdgcn_global_load_lds((glb_float*)(img + off), lp + k * RPI * C::PW, 16, 0, 0);
-                }
+            for (int k = 0; k < NI; ++k) {
+                if ((k + 1) * RPI <= C::PH || lr < C::PH - k * RPI)
+                    __builtin_amdgcn_global_load_lds((glb_float*)g, lp + k * RPI * C::PW, 16, 0, 0);
+                g += RPI * pitch;
             }
         }
     } else {
-        // a column border crosses the patch: 4-byte LDS-DMA, lane = patch column, columns clamped per lane
+        // anywhere else (positions outside the image, very wide windows at a border): 4-byte LDS-DMA, lane = patch
+        // column, rows and columns replicate-clamped
 #pragma unroll
         for (int c0 = 0; c0 < C::PW; c0 += 64) {
             const int c = c0 + lane;
             if (c < C::PW) {
                 const int cc = clampi(ou + c, 0, nu - 1);
-#pragma unroll
+#pragma unroll 1
                 for (int r = 0; r < C::PH; ++r) {
-                    const float* rowp = img + (long)clampi(ov + r, 0, nv - 1) * nu;
+                    const float* rowp = img + (long)clampi(ov + r, 0, nv - 1) * pitch;
                     __builtin_amdgcn_global_load_lds((glb_float*)(rowp + cc), lp + r * C::PW + c0, 4, 0, 0);
                 }
             }
@@ -220,15 +219,15 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     bool staged0 = false; // level 0: is a B patch staged, and where (re-used by the score)
     int pou0 = 0, pov0 = 0;
     for (int l = a.levels - 1; l >= 0; --l) {
-        int nu, nv; long lo;
-        level_dims(nu0, nv0, l, nu, nv, lo);
+        int nu, nv, pitch; long lo;
+        level_dims(nu0, nv0, l, nu, nv, lo, pitch);
         const double plu = ldexp(su, -l), plv = ldexp(sv, -l); // = su / 2^l, exact
         float sxx = 0, sxy = 0, syy = 0, ctu = 0, ctv = 0;
         {   // ---- template set-up: E = samples on the window grown by one pixel, Sobel/8 of E.
             // Rows stream through a 3-row ring so that only 3 x (BW+2) samples are live at a time.
             const double flu = floor(plu), flv = floor(plv);
             const float fu = unif((float)(plu - flu)), fv = unif((float)(plv - flv));
-            stage<C>(patch, A + lo, nu, nv, uni((int)flu) - ru - 1, uni((int)flv) - rv - 1, lane, lr, lq);
+            stage<C>(patch, A + lo, pitch, nu, nv, uni((int)flu) - ru - 1, uni((int)flv) - rv - 1, lane, lr, lq);
             // E rows stream through a 3-row ring.  Separable Sobel per template row: VD = vertical
             // difference, VS = vertical 1-2-1 smoothing of the three rows, then the horizontal halves.
             // Gradients are kept times 8 (the 1/8 of the operator is a power of two: it is folded,
@@ -319,7 +318,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                     int fi = iu - ru - pou, fj = iv - rv - pov;
                     if (!staged || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) {
                         pou = iu - ru - LK_M; pov = iv - rv - LK_M;
-                        stage<C>(patch, B + lo, nu, nv, pou, pov, lane, lr, lq);
+                        stage<C>(patch, B + lo, pitch, nu, nv, pou, pov, lane, lr, lq);
                         staged = true;
                         fi = LK_M; fj = LK_M;
                     }
@@ -377,12 +376,15 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     if (SCORE && !(flags & 1)) { // N5 residual at level 0: the match J first (the level-0 B patch is
                                  // usually still staged around it), then the re-sampled template
         float J[BH][BW];
+        constexpr int pitch0_pad = 2 * PYR_PAD;
+        const int pitch0 = nu0 + pitch0_pad;
+        const long lo0 = (long)PYR_PAD * pitch0 + PYR_PAD;   // level 0's pixel (0, 0)
         {
             const double flu = floor(qu), flv = floor(qv);
             const int iu = uni((int)flu), iv = uni((int)flv);
             int fi = iu - ru - pou0, fj = iv - rv - pov0;
             if (!staged0 || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) {
-                stage<C>(patch, B, nu0, nv0, iu - ru - LK_M, iv - rv - LK_M, lane, lr, lq);
+                stage<C>(patch, B + lo0, pitch0, nu0, nv0, iu - ru - LK_M, iv - rv - LK_M, lane, lr, lq);
                 fi = LK_M; fj = LK_M;
             }
             const float fu = unif((float)(qu - flu)), fv = unif((float)(qv - flv));
@@ -404,7 +406,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             }
         }
         const double flu = floor(su), flv = floor(sv);
-        stage<C>(patch, A, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane, lr, lq);
+        stage<C>(patch, A + lo0, pitch0, nu0, nv0, uni((int)flu) - ru - LK_M, uni((int)flv) - rv - LK_M, lane, lr, lq);
         const float fu = unif((float)(su - flu)), fv = unif((float)(sv - flv));
         const int base = lbase + LK_M * PW + LK_M;
         float ssd = 0;
