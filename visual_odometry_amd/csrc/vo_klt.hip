@@ -118,6 +118,24 @@ __device__ __forceinline__ void wave_sums(const float (&v)[N], float (&out)[N]) 
 __device__ __forceinline__ int mask_word(unsigned mlo, unsigned mhi, int bit) { // bit: a constant after unrolling
     return __builtin_amdgcn_sbfe((int)(bit < 32 ? mlo : mhi), (unsigned)(bit & 31), 1u); // v_bfe_i32: -1 or 0
 }
+// The window mask of a lane's block.  General form: one bit per pixel in a 64-bit word.  W41 form: the window is
+// (LU-1) BW + 1 wide and LV BH - 1 high (41 x 41 on 9 x 7 blocks of 5 x 6, the reference's BlockSize): only the last
+// column of blocks (columns 1.. outside) and the last row of blocks (last row outside) are cut, so four whole-word
+// masks -- lane alive / not in the last column of blocks / not in the last row of blocks / neither -- replace the
+// per-pixel bit extraction.
+template <bool W41> struct WinMask;
+template <> struct WinMask<false> {
+    unsigned lo, hi;
+    __device__ __forceinline__ void opaque() { asm volatile("" : "+v"(lo), "+v"(hi)); }
+    template <int BW, int BH> __device__ __forceinline__ int word(int i, int j) const { return mask_word(lo, hi, j * BW + i); }
+};
+template <> struct WinMask<true> {
+    int a, c, r, cr;
+    __device__ __forceinline__ void opaque() { asm volatile("" : "+v"(a), "+v"(c), "+v"(r), "+v"(cr)); }
+    template <int BW, int BH> __device__ __forceinline__ int word(int i, int j) const {
+        return i >= 1 ? (j == BH - 1 ? cr : c) : (j == BH - 1 ? r : a);
+    }
+};
 __device__ __forceinline__ float and_bits(float x, int m) { return __int_as_float(__float_as_int(x) & m); }
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -197,9 +215,9 @@ __device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin
 // one direction A -> B (N4).  returns flags: bit0 lost, bit1 flat at level 0.
 // Wave-uniform scalars (sub-pixel fractions, the 2x2 inverse, the running displacement) are pushed
 // back to SGPRs after every VALU step so that the register file holds little besides the template.
-template <class C, bool SCORE>
+template <class C, bool SCORE, bool W41>
 __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float* __restrict__ B, double su, double sv,
-                      float* patch, int lane, int lr, int lq, int lbase, unsigned long long mask, double& qu, double& qv, float& ssd_out,
+                      float* patch, int lane, int lr, int lq, int lbase, const WinMask<W41>& mask, double& qu, double& qv, float& ssd_out,
                       unsigned& iters, unsigned& setups, unsigned& cells) {
     constexpr int BW = C::BW, BH = C::BH, PW = C::PW;
     // The residual sum is split, b = sum T*(Tu,Tv) - sum J*(Tu,Tv): the first term is a constant of the
@@ -233,24 +251,35 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             // Gradients are kept times 8 (the 1/8 of the operator is a power of two: it is folded,
             // exactly, into G and the 2x2 inverse below).
             float E[3][BW + 2];
-            float hp[BW + 2];
             // opaque per-level copies: the mask words are re-extracted at each use (one v_bfe_i32) instead
             // of living in 30 registers across the kernel
-            unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
-            asm volatile("" : "+v"(mlo), "+v"(mhi));
+            WinMask<W41> wm = mask;
+            wm.opaque();
+            // Row-major lane order (lane + 1 = the block to the right): a lane samples only the BW columns that
+            // start its block and takes the two columns that complete its Sobel support -- the first two columns
+            // of its right neighbour, the same samples by the same arithmetic -- from lane + 1 (DPP wave shift).
+            // 5 instead of 7 columns of separable lerps per row and 6 instead of 8 LDS reads.  The last block of a
+            // row of blocks receives columns that lie outside the window: finite image samples, masked below.
+            constexpr int EC = C::COL ? BW + 2 : BW;   // columns of E this lane samples itself
+            float hp[EC];
 #pragma unroll
             for (int r = 0; r < BH + 3; ++r) {
-                float p[BW + 3];
+                float p[EC + 1];
 #pragma unroll
-                for (int c = 0; c < BW + 3; ++c) p[c] = patch[lbase + r * PW + c];
+                for (int c = 0; c < EC + 1; ++c) p[c] = patch[lbase + r * PW + c];
 #pragma unroll
-                for (int c = 0; c < BW + 2; ++c) p[c] = p[c] + fu * (p[c + 1] - p[c]); // p[c] := H(r, c)
+                for (int c = 0; c < EC; ++c) p[c] = p[c] + fu * (p[c + 1] - p[c]); // p[c] := H(r, c)
                 if (r > 0) {
+                    float* er = E[(r - 1) % 3];
 #pragma unroll
-                    for (int c = 0; c < BW + 2; ++c) E[(r - 1) % 3][c] = hp[c] + fv * (p[c] - hp[c]);
+                    for (int c = 0; c < EC; ++c) er[c] = hp[c] + fv * (p[c] - hp[c]);
+                    if (!C::COL) {
+                        er[BW] = dpp_mov<0x130, 0xf>(er[0]);       // wave_shl:1 -- lane i reads lane i + 1
+                        er[BW + 1] = dpp_mov<0x130, 0xf>(er[1]);
+                    }
                 }
 #pragma unroll
-                for (int c = 0; c < BW + 2; ++c) hp[c] = p[c];
+                for (int c = 0; c < EC; ++c) hp[c] = p[c];
                 if (r >= 3) { // E rows j, j+1, j+2 are complete: emit template row j
                     const int j = r - 3;
                     const float* e0 = E[j % 3]; const float* e1 = E[(j + 1) % 3]; const float* e2 = E[(j + 2) % 3];
@@ -262,7 +291,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                     }
 #pragma unroll
                     for (int i = 0; i < BW; ++i) {
-                        const int in = mask_word(mlo, mhi, j * BW + i);
+                        const int in = wm.template word<BW, BH>(i, j);
                         const float tu = VS[i + 2] - VS[i];
                         const float tv = (VD[i] + 2.0f * VD[i + 1]) + VD[i + 2];
                         Tu[j][i] = and_bits(tu, in);
@@ -411,8 +440,8 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
         const int base = lbase + LK_M * PW + LK_M;
         float ssd = 0;
         float hp[BW];
-        unsigned mlo = (unsigned)mask, mhi = (unsigned)(mask >> 32);
-        asm volatile("" : "+v"(mlo), "+v"(mhi));
+        WinMask<W41> wm = mask;
+        wm.opaque();
 #pragma unroll
         for (int r = 0; r < BH + 1; ++r) {
             float p[BW + 1];
@@ -423,7 +452,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             if (r > 0) {
 #pragma unroll
                 for (int c = 0; c < BW; ++c) {
-                    const int in = mask_word(mlo, mhi, (r - 1) * BW + c);
+                    const int in = wm.template word<BW, BH>(c, r - 1);
                     const float e = and_bits((hp[c] + fv * (p[c] - hp[c])) - J[r - 1][c], in);
                     ssd += e * e;
                 }
@@ -436,7 +465,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     return flags;
 }
 
-template <class C>
+template <class C, bool W41>
 __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
     __shared__ __attribute__((aligned(16))) float patch[C::PW * C::PH];
     const int lane = threadIdx.x, kp = blockIdx.x;
@@ -448,23 +477,32 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
     const int lbase = live ? (lv * C::BH) * C::PW + lu * C::BW : 0;
     // bit (j * BW + i) = pixel (i, j) of this lane's block lies inside the wu x wv window
     static_assert(C::BW * C::BH <= 64, "block mask does not fit");
-    unsigned long long mask64 = 0;
-    if (live) {
+    WinMask<W41> wmask;
+    if constexpr (W41) {
+        wmask.a = live ? -1 : 0;
+        wmask.c = (live && lu < C::LU - 1) ? -1 : 0;
+        wmask.r = (live && lv < C::LV - 1) ? -1 : 0;
+        wmask.cr = wmask.c & wmask.r;
+    } else {
+        unsigned long long mask64 = 0;
+        if (live) {
 #pragma unroll
-        for (int j = 0; j < C::BH; ++j)
+            for (int j = 0; j < C::BH; ++j)
 #pragma unroll
-            for (int i = 0; i < C::BW; ++i)
-                if (lu * C::BW + i < a.wu && lv * C::BH + j < a.wv) mask64 |= 1ull << (j * C::BW + i);
+                for (int i = 0; i < C::BW; ++i)
+                    if (lu * C::BW + i < a.wu && lv * C::BH + j < a.wv) mask64 |= 1ull << (j * C::BW + i);
+        }
+        wmask.lo = (unsigned)mask64; wmask.hi = (unsigned)(mask64 >> 32);
     }
     const double p0u = a.pu[kp], p0v = a.pv[kp];
     unsigned iters = 0, setups = 0, cells = 0;
     double fu, fv, bu = 0, bv = 0;
     float ssd, ssd2;
-    const int fl = lk_dir<C, true>(a, a.A, a.B, p0u, p0v, patch, lane, lr, lq, lbase, mask64, fu, fv, ssd, iters, setups, cells);
+    const int fl = lk_dir<C, true, W41>(a, a.A, a.B, p0u, p0v, patch, lane, lr, lq, lbase, wmask, fu, fv, ssd, iters, setups, cells);
     bool ok = (fl == 0);
     float fb = __builtin_nanf("");
     if (!(fl & 1) && a.max_bidir >= 0.0) {
-        const int fl2 = lk_dir<C, false>(a, a.B, a.A, fu, fv, patch, lane, lr, lq, lbase, mask64, bu, bv, ssd2, iters, setups, cells);
+        const int fl2 = lk_dir<C, false, W41>(a, a.B, a.A, fu, fv, patch, lane, lr, lq, lbase, wmask, bu, bv, ssd2, iters, setups, cells);
         if (fl2 & 1) ok = false;
         else {
             const double eu = p0u - bu, ev = p0v - bv;
@@ -495,7 +533,9 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
 
 template <class C>
 void launch(const LKArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_lk<C>, dim3(a.n), dim3(64), 0, st, a);
+    // the window that cuts only the last column / row of blocks the way WinMask<true> assumes
+    if (a.wu == (C::LU - 1) * C::BW + 1 && a.wv == C::LV * C::BH - 1) hipLaunchKernelGGL((k_lk<C, true>), dim3(a.n), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_lk<C, false>), dim3(a.n), dim3(64), 0, st, a);
 }
 
 } // namespace
