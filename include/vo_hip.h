@@ -110,8 +110,11 @@ int vo_ctx_sync(vo_ctx* ctx);
  * so far; after _end the calls go to the ctx stream again and run beside the lane; vo_ctx_lane_join makes the ctx
  * stream wait for the lane's work (call it before the first consumer of the lane's results).  Scheduling only: the
  * results are those of the same calls made in order on one stream.  Pyramids issued ahead (vo_dev_frame_prefetch)
- * that both branches read: make the ctx stream wait for them first (vo_dev_frame_wait). */
+ * that both branches read: make the ctx stream wait for them first (vo_dev_frame_wait).  vo_ctx_lane_resume reopens
+ * the lane behind its own earlier work without a new dependency on the ctx stream (to enqueue the other branch's
+ * first launch before the rest of the lane's: the host then feeds both streams early). */
 int vo_ctx_lane_begin(vo_ctx* ctx);
+int vo_ctx_lane_resume(vo_ctx* ctx);
 int vo_ctx_lane_end(vo_ctx* ctx);
 int vo_ctx_lane_join(vo_ctx* ctx);
 const char* vo_ctx_last_error(vo_ctx* ctx);

@@ -20,9 +20,13 @@ ctx = _lib.Context(0)
 wl = FrameWorkload(ctx, 25000, 25000, n_frames=2, num_hyp=8, ahead=False)
 wl.build(1, 1)
 res = {}
-for tag, blk in (("41", 41), ("21", 21), ("31", 31), ("51", 51)):
-    wl.block = blk
-    n = 50000 if blk == 41 else 3000
-    wl.track(0, 1, wl.pa[:, :n], wl.qa[:, :n], wl.va[:n], wl.sa[:n]); wl.sync()
+def track(n, wu, wv):
+    ctx.call("vo_dev_klt_track", 0, 1, _p(wl.pa[0]), _p(wl.pa[1]), n, wu, wv, 50, C.c_double(0.01), C.c_double(2.0),
+             _p(wl.qa[0]), _p(wl.qa[1]), _p(wl.va), _p(wl.sa), None)
+    wl.sync()
+for tag, (wu, wv) in (("41", (41, 41)), ("21", (21, 21)), ("31", (31, 31)), ("51", (51, 51)), ("35x31", (35, 31)), ("33x29", (33, 29)),
+                      ("45x41", (45, 41)), ("43x37", (43, 37)), ("7", (7, 7)), ("19x21", (19, 21))):
+    n = 50000 if tag == "41" else 3000
+    track(n, wu, wv)
     res["q" + tag] = wl.qa[:, :n].cpu().numpy(); res["v" + tag] = wl.va[:n].cpu().numpy(); res["s" + tag] = wl.sa[:n].cpu().numpy()
 np.savez(sys.argv[2], **res)

@@ -156,6 +156,14 @@ int vo_ctx_lane_begin(vo_ctx* ctx) {
     ctx->in_lane = true;
     return VO_OK;
 }
+int vo_ctx_lane_resume(vo_ctx* ctx) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    if (ctx->in_lane || !ctx->lane) { ctx->last_error = "vo_ctx_lane_resume: no lane to resume (or one is open)"; return VO_ERR_BAD_ARG; }
+    ctx->lane_saved = ctx->stream;
+    ctx->stream = ctx->lane;
+    ctx->in_lane = true;
+    return VO_OK;
+}
 int vo_ctx_lane_end(vo_ctx* ctx) {
     if (!ctx) return VO_ERR_BAD_ARG;
     if (!ctx->in_lane) { ctx->last_error = "vo_ctx_lane_end: no lane is open"; return VO_ERR_BAD_ARG; }

@@ -259,8 +259,12 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             // start its block and takes the two columns that complete its Sobel support -- the first two columns
             // of its right neighbour, the same samples by the same arithmetic -- from lane + 1 (DPP wave shift).
             // 5 instead of 7 columns of separable lerps per row and 6 instead of 8 LDS reads.  The last block of a
-            // row of blocks receives columns that lie outside the window: finite image samples, masked below.
-            constexpr int EC = C::COL ? BW + 2 : BW;   // columns of E this lane samples itself
+            // row of blocks has no such neighbour (lane + 1 is the first block of the next row): what it receives
+            // must only reach masked pixels, which holds when the window leaves that block at most BW - 2 columns
+            // -- the W41 window shape leaves it one (35 x 31 on the same blocks fills it: found by
+            // test_klt_window_classes_and_borders).  Other shapes sample all BW + 2 columns themselves.
+            constexpr bool SHARE = W41 && !C::COL && BW >= 3;
+            constexpr int EC = SHARE ? BW : BW + 2;   // columns of E this lane samples itself
             float hp[EC];
 #pragma unroll
             for (int r = 0; r < BH + 3; ++r) {
@@ -273,7 +277,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                     float* er = E[(r - 1) % 3];
 #pragma unroll
                     for (int c = 0; c < EC; ++c) er[c] = hp[c] + fv * (p[c] - hp[c]);
-                    if (!C::COL) {
+                    if (SHARE) {
                         er[BW] = dpp_mov<0x130, 0xf>(er[0]);       // wave_shl:1 -- lane i reads lane i + 1
                         er[BW + 1] = dpp_mov<0x130, 0xf>(er[1]);
                     }

@@ -307,15 +307,17 @@ struct ScoreArgs {
     const int32_t* M_dev;   // as in HypArgs
 };
 
-// Scores 8 poses per block on a range of the points and ADDS what it finds to cnt / cost (zeroed by the launcher):
+// Scores 8 poses per block on a range of the points and ADDS what it finds to cnt / cost (zeroed by k_zero):
 // the inlier count, and the MSAC cost of the range = inlier terms + (points of the range - inliers) * qthr.  All
 // sums are integers, so any split of the points over blocks and launches gives the same totals.
-__global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
+// One wave per block, under 1 KB of LDS and 128 VGPRs: beside a tracking launch that fills the chip with one-wave
+// workgroups (vo_ctx_lane_*), such a block fits the hole any finished tracking wave leaves; a 256-thread block had to
+// wait for four holes on one CU at once and starved (as did the runtime's memset kernel: hence k_zero).
+constexpr int SC_NT = 64;
+__global__ __launch_bounds__(SC_NT) void k_score(ScoreArgs a) {
     VO_POSE_PRIO();
     __shared__ double sRt[SC_NS * 12];
     __shared__ int s_pid[SC_NS];
-    __shared__ int s_cnt[4][SC_NS];
-    __shared__ unsigned long long s_cost[4][SC_NS];
     if (a.stopped && *a.stopped) return;   // uniform: the whole launch has nothing to do
     if (a.M_dev) { a.M = min(a.M, *a.M_dev); if (a.M < 4) return; }
     const int tid = threadIdx.x;
@@ -328,11 +330,11 @@ __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
         s_pid[tid] = pid;
     }
     __syncthreads();
-    if (tid < SC_NS * 12) {
-        const int hs = tid / 12;             // pose within the block
-        const int e = tid - 12 * hs;         // element of the pose's 3x4 projection
+    for (int k = tid; k < SC_NS * 12; k += SC_NT) {
+        const int hs = k / 12;               // pose within the block
+        const int e = k - 12 * hs;           // element of the pose's 3x4 projection
         const int pid = s_pid[hs];
-        sRt[tid] = pid >= 0 ? proj_elem(a.Rt + 12 * (long)pid, a.K, e >> 2, e & 3) : 0.0;
+        sRt[k] = pid >= 0 ? proj_elem(a.Rt + 12 * (long)pid, a.K, e >> 2, e & 3) : 0.0;
     }
     __syncthreads();
     const long r0 = (long)a.M * a.q0 / 8, r1 = (long)a.M * a.q1 / 8;
@@ -345,12 +347,12 @@ __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
 #pragma unroll
     for (int s = 0; s < SC_NS; ++s) { cnt[s] = 0; cost[s] = 0; }
     // SC_PT points per thread and pass: a pose read from LDS serves all of them
-    for (int i0 = c0 + tid; i0 < c1; i0 += 256 * SC_PT) {
+    for (int i0 = c0 + tid; i0 < c1; i0 += SC_NT * SC_PT) {
         double X0[SC_PT], X1[SC_PT], X2[SC_PT], u[SC_PT], v[SC_PT];
         bool has[SC_PT];
 #pragma unroll
         for (int p = 0; p < SC_PT; ++p) {
-            const int i = i0 + 256 * p;
+            const int i = i0 + SC_NT * p;
             has[p] = i < c1;
             const int j = has[p] ? i : i0;
             X0[p] = a.X[j * a.sX.xi]; X1[p] = a.X[j * a.sX.xi + a.sX.xc]; X2[p] = a.X[j * a.sX.xi + 2 * a.sX.xc];
@@ -381,24 +383,25 @@ __global__ __launch_bounds__(256) void k_score(ScoreArgs a) {
             }
         }
     }
-    const int lane = tid & 63, wid = tid >> 6;
+    if (c1 <= c0) return;
 #pragma unroll
     for (int s = 0; s < SC_NS; ++s) {
         int c = cnt[s]; unsigned long long q = cost[s];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { c += __shfl_xor(c, d, 64); q += __shfl_xor(q, d, 64); }
-        if (lane == 0) { s_cnt[wid][s] = c; s_cost[wid][s] = q; }
-    }
-    __syncthreads();
-    if (tid < SC_NS && s_pid[tid] >= 0 && c1 > c0) {
-        const int c = (s_cnt[0][tid] + s_cnt[1][tid]) + (s_cnt[2][tid] + s_cnt[3][tid]);
-        const unsigned long long q = (s_cost[0][tid] + s_cost[1][tid]) + (s_cost[2][tid] + s_cost[3][tid]) +
-                                     (unsigned long long)((c1 - c0) - c) * qthr;
-        if (c) atomicAdd(&a.cnt[s_pid[tid]], c);
-        atomicAdd(&a.cost[s_pid[tid]], q);
+        if (tid == s && s_pid[s] >= 0) {
+            if (c) atomicAdd(&a.cnt[s_pid[s]], c);
+            atomicAdd(&a.cost[s_pid[s]], q + (unsigned long long)((c1 - c0) - c) * qthr);
+        }
     }
     if (tid == 0 && a.counters && !a.list && blockIdx.y == 0)
         atomicAdd(&a.counters[4 * (blockIdx.x & (VO_COUNTER_SHARDS - 1)) + 3], (unsigned long long)min(SC_HB, a.H - (a.h0 + (int)blockIdx.x * SC_HB)));
+}
+
+// zeroes the run's sums (counts, costs, the bound and survivor-count words): one-wave blocks, see k_score
+__global__ __launch_bounds__(64) void k_zero(unsigned* p, long nwords) {
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;
+    if (i < nwords) p[i] = 0u;
 }
 
 // Which poses of the hypotheses [h0, H) can still become the record after `seen` eighths of the points?
@@ -414,10 +417,11 @@ struct SurvArgs {
     const int32_t* cnt; const unsigned long long* cost; const unsigned long long* bound; int h0, H, M, mode, seen;
     const int32_t* in; const int32_t* in_n; int32_t* list; int32_t* list_n; const int32_t* stopped; const int32_t* M_dev;
 };
-__global__ __launch_bounds__(256) void k_survivors(SurvArgs a) {
+__global__ __launch_bounds__(64) void k_survivors(SurvArgs a) {
+    VO_POSE_PRIO();
     if (a.stopped && *a.stopped) return;
     if (a.M_dev) { a.M = min(a.M, *a.M_dev); if (a.M < 4) return; }
-    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.x * 64 + threadIdx.x;
     int pid;
     if (a.in) { if (k >= *a.in_n) return; pid = a.in[k]; }
     else { pid = 4 * a.h0 + k; if (pid >= 4 * a.H) return; }
@@ -574,9 +578,9 @@ struct InlArgs {
     const int32_t* M_dev;   // as in HypArgs (flags beyond the device count are written as 0)
     double* pose_out;       // optional: the pose [R_WC; t_WC] of the record (modules/VisualOdometry.m:318), C = -R_cw^T t_cw
 };
-__global__ __launch_bounds__(256) void k_inliers(InlArgs a) {
+__global__ __launch_bounds__(64) void k_inliers(InlArgs a) {
     VO_POSE_PRIO();
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 64 + threadIdx.x;
     int32_t* info = (int32_t*)(a.out + 12);
     if (i == 0 && a.pose_out) {
         const double* out = a.out;
@@ -610,9 +614,10 @@ __global__ __launch_bounds__(64) void k_p3p_batch(const double* P, const double*
 } // namespace
 
 static int score_chunks(int nblocks, int npoints) {
-    // split the points over blockIdx.y when there are few hypotheses, so that a short launch still fills the chip
+    // one-wave blocks: split the points over blockIdx.y until the launch has about 4 waves per SIMD (a piece no
+    // shorter than 1024 points = 4 passes of a wave)
     int c = 1;
-    while (c < 8 && nblocks * c < 768 && npoints / (2 * c) >= 2048) c *= 2;
+    while (c < 64 && nblocks * c < 3072 && npoints / (2 * c) >= 1024) c *= 2;
     return c;
 }
 
@@ -637,7 +642,10 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
     // without a confidence nothing can end the run early: a short first stage is enough to set the bound, and all
     // hypotheses are generated in one launch
     const int S = o->confidence > 0 ? RANSAC_STAGE : RANSAC_STAGE / 4;
-    VO_HIP_CHECK(ctx, hipMemsetAsync(w->cnt, 0, w->zero_bytes, ctx->stream));   // counts, costs, bound, list length
+    {   // counts, costs, bound, list lengths start at zero
+        const long nwords = (long)(w->zero_bytes / 4);
+        hipLaunchKernelGGL(k_zero, dim3((unsigned)((nwords + 63) / 64)), dim3(64), 0, ctx->stream, (unsigned*)w->cnt, nwords);
+    }
     auto hyp = [&](int h0, int h1, bool later) {
         if (d_poses_in) return;
         HypArgs h;
@@ -655,8 +663,8 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
         // survivor launches: few blocks do anything (how few is known on the device only), so each takes a short
         // piece of the range -- the launch is as long as one block
         const int npts = (int)((long)M * (q1 - q0) / 8);
-        const int chunks = from_list ? (npts >= 8 * 512 ? 8 : 1) : score_chunks(nb, npts);
-        hipLaunchKernelGGL(k_score, dim3(nb, chunks), dim3(256), 0, ctx->stream, s);
+        const int chunks = from_list ? (npts >= 16 * 512 ? 16 : (npts >= 2048 ? 4 : 1)) : score_chunks(nb, npts);
+        hipLaunchKernelGGL(k_score, dim3(nb, chunks), dim3(SC_NT), 0, ctx->stream, s);
     };
     auto best = [&](int h1, int later, bool write_bound) {
         BestArgs b;
@@ -679,17 +687,17 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
         sv.cnt = w->cnt; sv.cost = w->cost; sv.bound = w->bound; sv.h0 = S; sv.H = H; sv.M = M; sv.mode = o->mode;
         sv.stopped = stopped; sv.M_dev = d_M;
         sv.seen = 3; sv.in = nullptr; sv.in_n = nullptr; sv.list = w->list; sv.list_n = w->list_n;
-        hipLaunchKernelGGL(k_survivors, dim3((4 * (H - S) + 255) / 256), dim3(256), 0, ctx->stream, sv);
+        hipLaunchKernelGGL(k_survivors, dim3((4 * (H - S) + 63) / 64), dim3(64), 0, ctx->stream, sv);
         score(S, H, 3, 6, true, 1);                     // the survivors on the next 3/8
         sv.seen = 6; sv.in = w->list; sv.in_n = w->list_n; sv.list = w->list + 4 * (size_t)H; sv.list_n = w->list_n + 1;
-        hipLaunchKernelGGL(k_survivors, dim3((4 * (H - S) + 255) / 256), dim3(256), 0, ctx->stream, sv);
+        hipLaunchKernelGGL(k_survivors, dim3((4 * (H - S) + 63) / 64), dim3(64), 0, ctx->stream, sv);
         score(S, H, 6, 8, true, 2);                     // what is left on the last quarter
         best(H, 1, false);
     }
     InlArgs in;
     in.xy = d_xy; in.sxy = sxy; in.X = d_X; in.sX = sX; in.M = M; in.K = d_K; in.thr2 = thr2; in.out = (double*)d_out;
     in.inliers = d_inliers; in.M_dev = d_M; in.pose_out = d_pose_out;
-    hipLaunchKernelGGL(k_inliers, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, in);
+    hipLaunchKernelGGL(k_inliers, dim3((M + 63) / 64), dim3(64), 0, ctx->stream, in);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }
@@ -703,7 +711,7 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
 // with that device current) and from then on only the looked-up pointer is used -- the array's NAME is a host-side
 // stand-in, not a device address.  All calls on one GPU share the array: calls that overlap on one GPU (two ctxs,
 // two threads) race.  The launcher zeroes what must start at zero (counts, costs, the survivor count) with one
-// hipMemsetAsync on the looked-up pointer at the start of every run.
+// small kernel (k_zero) on the looked-up pointer at the start of every run.
 namespace {
 constexpr size_t static_pad(size_t b) { return (b + 255) & ~(size_t)255; }
 constexpr size_t STATIC_RT = static_pad((size_t)VO_STATIC_MAX_HYP * 48 * sizeof(double));

@@ -144,9 +144,11 @@ class FrameWorkload:
             self.ctx.call("vo_dev_frame_wait", a); self.ctx.call("vo_dev_frame_wait", b)
             self.ctx.call("vo_ctx_lane_begin")
             self.track_landmarks(a, b)
+            self.ctx.call("vo_ctx_lane_end")
+            self.track_candidates(a, b)          # enqueued before the pose chain's dozen launches: both streams fed early
+            self.ctx.call("vo_ctx_lane_resume")
             self.pose()
             self.ctx.call("vo_ctx_lane_end")
-            self.track_candidates(a, b)
         else:
             if lap:
                 self.ctx.lap_begin()
