@@ -445,6 +445,23 @@ __global__ __launch_bounds__(UNI_NT) void k_uniform(UniArgs a) {
         if (t == 0) *a.out_count = S;
         return;
     }
+    if (all && nl <= UNI_LDS_CELLS) {
+        // every surviving corner is selected and there are few of them (the usual case beside tens of thousands of
+        // existing points): the compact list goes through LDS, each entry finds its rank by counting the smaller
+        // indices -- ascending corner index, as the ordered compaction below produces
+        for (int e = t; e < nl; e += UNI_NT) s_idx[e] = a.klist[e];
+        __syncthreads();
+        for (int e = t; e < nl; e += UNI_NT) {
+            const int i = s_idx[e];
+            int pos = 0;
+            for (int j = 0; j < nl; ++j) pos += s_idx[j] < i ? 1 : 0;
+            a.out_u[pos] = a.cu[i]; a.out_v[pos] = a.cv[i];
+            if (a.out_lin) a.out_lin[pos] = a.lin[i];
+            if (a.out_metric) a.out_metric[pos] = a.metric[i];
+        }
+        if (t == 0) *a.out_count = nl;
+        return;
+    }
     for (int i = t; i < m; i += UNI_NT) a.sel[i] = all ? a.keep[i] : 0;
     __threadfence_block();
     __syncthreads();
