@@ -121,6 +121,16 @@ const char* vo_ctx_last_error(vo_ctx* ctx);
 /* counters: [0] LK iterations executed (window passes), [1] keypoints tracked, [2] LK template
  * set-ups (level x direction x point), [3] hypotheses scored */
 int vo_ctx_read_counters(vo_ctx* ctx, uint64_t out[4], int reset);
+/* Run statistics of sequence-sharded runs (one sequence per GPU, module_tests/VisualOdometry_test.m:88-103
+ * is the loop that is sharded; the only collective of the whole path).  Every rank passes its own record; all ranks get
+ * the job's record back: counters summed, elapsed_s = the slowest rank's.  comm: an ncclComm_t of RCCL made by the caller
+ * (any host language: ncclCommInitRank with one rank per GPU), NULL for a single rank (the record comes back unchanged).
+ * RCCL is looked up at call time in the process (the copy the host already loaded, else librccl.so): the library itself
+ * does not link against it.  Two ncclAllReduce of five doubles on the ctx stream, then one small copy back. */
+typedef struct vo_stats {
+    double frames, keypoints_tracked, keypoints_valid, ransac_inliers, elapsed_s;
+} vo_stats;
+int vo_stats_gather(vo_ctx* ctx, void* rccl_comm, const vo_stats* local, vo_stats* job);
 /* HIP-event stopwatch on the ctx stream (bench.py's live kernel timing) */
 int vo_timer_start(vo_ctx* ctx);
 int vo_timer_stop_ms(vo_ctx* ctx, float* ms);
@@ -213,7 +223,8 @@ int vo_essential_ransac(vo_ctx* ctx, vo_layout lay, const double* pts0, const do
  * points structure-of-arrays. ==== */
 
 #define VO_NUM_FRAME_SLOTS 4
-/* build the float pyramid + Sobel gradients of a device image into a frame slot */
+/* build the float pyramid of a device image into a frame slot (no gradient planes: the tracker differentiates the
+ * sampled template) */
 int vo_dev_frame_build(vo_ctx* ctx, int slot, const uint8_t* d_img, int nu, int nv, int levels);
 /* track slot_a -> slot_b; wu/wv = window along u / v */
 int vo_dev_klt_track(vo_ctx* ctx, int slot_a, int slot_b, const double* d_pu, const double* d_pv, int n,

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
 #include <new>
 #include <vector>
 
@@ -66,7 +67,7 @@ int vo_ctx_create(int device, vo_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void**)&c->d_counters, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long) + 256) != hipSuccess   /* + vo_stats_gather's staging */ ||
         hipMemset(c->d_counters, 0, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long)) != hipSuccess) {
         vo_ctx_destroy(c);
         return VO_ERR_HIP;
@@ -196,6 +197,41 @@ int vo_ctx_read_counters(vo_ctx* ctx, uint64_t out[4], int reset) {
         for (int k = 0; k < 4; ++k) out[k] += h[4 * s + k];
     return VO_OK;
 }
+// ---- statistics collective (RCCL, resolved at call time) ----
+int vo_stats_gather(vo_ctx* ctx, void* rccl_comm, const vo_stats* local, vo_stats* job) {
+    if (!ctx || !local || !job) return VO_ERR_BAD_ARG;
+    *job = *local;
+    if (!rccl_comm) return VO_OK;   // one rank
+    // ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    // ncclFloat64 = 8, ncclSum = 0, ncclMax = 2 (rccl.h)
+    typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static allreduce_fn fn = nullptr;
+    if (!fn) {
+        fn = (allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");       // the RCCL the host process already holds
+        if (!fn) {
+            void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
+        }
+        if (!fn) { ctx->last_error = "vo_stats_gather: no RCCL in the process and librccl.so cannot be loaded"; return VO_ERR_UNSUPPORTED; }
+    }
+    (void)hipSetDevice(ctx->device);
+    double* d = (double*)ctx->d_counters;   // not the counters themselves: a 160-byte staging area behind them
+    d += VO_COUNTER_SHARDS * 4;
+    double h[5] = {local->frames, local->keypoints_tracked, local->keypoints_valid, local->ransac_inliers, local->elapsed_s};
+    VO_HIP_CHECK(ctx, hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+    if (fn(d, d + 5, 5, 8, 0, rccl_comm, ctx->stream) != 0 || fn(d, d + 10, 5, 8, 2, rccl_comm, ctx->stream) != 0) {
+        ctx->last_error = "vo_stats_gather: ncclAllReduce failed";
+        return VO_ERR_HIP;
+    }
+    double r[10];
+    VO_HIP_CHECK(ctx, hipMemcpyAsync(r, d + 5, sizeof r, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    job->frames = r[0]; job->keypoints_tracked = r[1]; job->keypoints_valid = r[2]; job->ransac_inliers = r[3];
+    job->elapsed_s = r[9];
+    return VO_OK;
+}
+
 int vo_timer_start(vo_ctx* ctx) {
     if (!ctx) return VO_ERR_BAD_ARG;
     VO_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
