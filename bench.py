@@ -26,47 +26,55 @@ FLOP_SETUP_PX, FLOP_ITER_PX = 24, 11      # algorithmic flops pe
 FP32_PEAK_TFLOPS = 157.3                  # MI355X_MICROARCH.md: fp32 vector peak = fp32-input MFMA peak
 
 
-def cpu_baseline(args, frames, budget_s=12.0, max_frames=24):
-    """The oracle (CPU restatement, kind 'port') on whole frames of the same workload -- KLT of all
-    keypoints, P3P-RANSAC at full size, triangulation, selection -- repeated over consecutive frame
-    pairs until about `budget_s` seconds of CPU work are done."""
+def cpu_baseline(args, frames, budget_s=14.0, min_frames=5, max_frames=24):
+    """The oracle (CPU restatement, kind 'port') on whole frames of the same workload -- KLT of all keypoints,
+    P3P-RANSAC at full size, triangulation, selection -- on consecutive frame pairs: 1 warm-up frame, then at least
+    `min_frames` timed frames (more while the budget lasts); the MEDIAN frame time is reported.  Built
+    -O3 -march=native on this host for this leg, OpenMP in every stage."""
+    import statistics
     import numpy as np
     from oracle import oracle
     from visual_odometry_amd import synth
-    threads = min(16, os.cpu_count() or 1)
+    build = oracle.use_timing_build()
+    host_cpus = os.cpu_count() or 1
+    threads = min(16, host_cpus)               # the box's CPU share for one GPU is 16 (os.cpu_count() shows the whole machine)
     nl = args.keypoints // 2
     pu, pv = synth.keypoints(args.keypoints)
     xy, X, *_ = synth.pnp_scene(nl)
     xy0, xy1, poses0, pose1, _ = synth.triangulation_scene(args.keypoints - nl)
     eu, ev = pu.astype("float32"), pv.astype("float32")
-    def run(n_threads, budget, max_n):
-        parts = {"klt": 0.0, "ransac": 0.0, "triangulate": 0.0, "select": 0.0}
-        done = 0
-        t_all = time.perf_counter()
-        while done < max_n and (done == 0 or time.perf_counter() - t_all < budget):
-            fa, fb = frames[done % (len(frames) - 1)], frames[done % (len(frames) - 1) + 1]
-            t0 = time.perf_counter()
-            oracle.klt_track(fa, fb, pu, pv, threads=n_threads)
-            t1 = time.perf_counter()
-            oracle.p3p_ransac(xy, X, synth.KITTI_K, num_hyp=args.hyp, mode=1, min_inliers=4, threads=n_threads)
-            t2 = time.perf_counter()
-            oracle.triangulate(xy0, xy1, poses0, pose1, synth.KITTI_K)
-            t3 = time.perf_counter()
-            oracle.select_candidates(fb, eu, ev, keep=100)
-            t4 = time.perf_counter()
-            parts["klt"] += t1 - t0; parts["ransac"] += t2 - t1; parts["triangulate"] += t3 - t2; parts["select"] += t4 - t3
-            done += 1
-        return done, time.perf_counter() - t_all, parts
 
-    done, total, parts = run(threads, budget_s, max_frames)
-    d1, t1s, _ = run(1, 0.0, 1)          # SURVEY 8(d): also single-threaded, one whole frame
-    return {"value": args.keypoints * done / total, "unit": "keypoints/s", "cores": threads, "kind": "port",
-            "frames_per_s": done / total,
-            "single_thread": {"value": args.keypoints * d1 / t1s, "unit": "keypoints/s", "frames_per_s": d1 / t1s,
-                              "sample": f"{d1} whole frame in {t1s:.1f} s on 1 thread"},
-            "sample": f"oracle (C, -O2, OpenMP {threads} threads; triangulation and selection single-threaded): {done} whole "
-                      f"frame(s) of the bench workload in {total:.1f} s (KLT {parts['klt']:.1f} s, RANSAC {parts['ransac']:.1f} s, "
-                      f"triangulation {parts['triangulate']:.1f} s, selection {parts['select']:.1f} s), nothing scaled"}
+    def one_frame(k, n_threads):
+        oracle.set_threads(n_threads)
+        fa, fb = frames[k % (len(frames) - 1)], frames[k % (len(frames) - 1) + 1]
+        t0 = time.perf_counter()
+        oracle.klt_track(fa, fb, pu, pv, threads=n_threads)
+        t1 = time.perf_counter()
+        oracle.p3p_ransac(xy, X, synth.KITTI_K, num_hyp=args.hyp, mode=1, min_inliers=4, threads=n_threads)
+        t2 = time.perf_counter()
+        oracle.triangulate(xy0, xy1, poses0, pose1, synth.KITTI_K)
+        t3 = time.perf_counter()
+        oracle.select_candidates(fb, eu, ev, keep=100)
+        t4 = time.perf_counter()
+        return t4 - t0, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)
+
+    one_frame(0, threads)                                     # warm-up
+    times, parts = [], []
+    t_all = time.perf_counter()
+    while len(times) < max_frames and (len(times) < min_frames or time.perf_counter() - t_all < budget_s):
+        t, p = one_frame(len(times) + 1, threads)
+        times.append(t); parts.append(p)
+    med = statistics.median(times)
+    pm = [statistics.median(x) for x in zip(*parts)]
+    t1s, _ = one_frame(1, 1)                                  # SURVEY 8(d): also single-threaded, one whole frame
+    oracle.set_threads(1)
+    return {"value": args.keypoints / med, "unit": "keypoints/s", "cores": threads, "kind": "port",
+            "frames_per_s": 1.0 / med, "host_cpus": host_cpus, "build": build,
+            "single_thread": {"value": args.keypoints / t1s, "unit": "keypoints/s", "frames_per_s": 1.0 / t1s,
+                              "sample": f"1 whole frame in {t1s:.1f} s on 1 thread"},
+            "sample": f"oracle (C, {build}, OpenMP {threads} threads in every stage): median of {len(times)} whole frames of the bench "
+                      f"workload after 1 warm-up frame, {med * 1e3:.0f} ms per frame (KLT {pm[0] * 1e3:.0f} ms, RANSAC {pm[1] * 1e3:.0f} ms, "
+                      f"triangulation {pm[2] * 1e3:.0f} ms, selection {pm[3] * 1e3:.0f} ms), nothing scaled"}
 
 
 def small_workload_leg(ctx, args, FrameWorkload, keypoints=2000, steps=300):
@@ -307,21 +315,35 @@ def main():
         it, kp, su, _ = ctx.counters(reset=True)
         flops = WINDOW_PX * (FLOP_ITER_PX * it + FLOP_SETUP_PX * su) / (respin + reps)   # the counters saw every launch since the reset
         ach = flops / (ms * 1e-3) / 1e12
-        traffic = None
-        try:  # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same kernel / workload
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_k_lk_pmc.json")))
-            if pmc.get("keypoints_per_launch") == args.keypoints:
+        # HBM-side bytes per launch and the VALU issue utilisation come from the rocprofv3 --pmc passes over this same
+        # kernel and workload (scripts/profile_round.sh -> profiles/round2_k_lk_pmc.json); they are quoted only while the
+        # kernel's sources are the ones that were profiled (sha256 in the file)
+        traffic = valu_util = None
+        pmc_note = "no PMC summary for this build of k_lk: traffic and valu_util not quoted"
+        try:
+            import hashlib
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_k_lk_pmc.json")))
+            sha = hashlib.sha256()
+            for f in ("vo_klt.hip", "vo_image.hip", "vo_common.h"):
+                sha.update(open(os.path.join(ROOT, "visual_odometry_amd", "csrc", f), "rb").read())
+            if pmc.get("keypoints_per_launch") == args.keypoints and pmc.get("source_sha256") == sha.hexdigest():
                 traffic = pmc["hbm_bytes_per_launch"]
+                valu_util = pmc.get("valu_issue_util")
+                pmc_note = ("traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch (fabric-side, Infinity-Cache hits included; "
+                            "FETCH_SIZE doubled for the 16-B/lane loads) and valu_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x "
+                            "GRBM_GUI_ACTIVE / 8) from profiles/round2_k_lk_pmc.json, PMC passes of this same kernel source")
         except (OSError, ValueError, KeyError):
             pass
-        roof = {"bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
-                "traffic": traffic, "kernel": "k_lk<41x41>", "launch_ms": ms, "keypoints_per_launch": args.keypoints,
+        roof = {"bound": "valu", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
+                "traffic": traffic, "valu_util": valu_util, "kernel": "k_lk<41x41>", "launch_ms": ms,
+                "keypoints_per_launch": args.keypoints,
                 "launches_timed": reps, "iters_per_keypoint": it / max(kp, 1), "setups_per_keypoint": su / max(kp, 1),
-                "note": "fp32 VALU-bound kernel, no MFMA used (nothing here is a dense contraction); peak = fp32 "
-                        "vector rate = fp32-input MFMA rate; flops = 1681 px x (11/iteration + 24/set-up), SURVEY 8d; "
-                        "launch_ms = HIP events around the KLT launch inside whole frame steps, read back once at the end; "
-                        "traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch from profiles/round1_k_lk_pmc.json "
-                        "(fabric-side, Infinity-Cache hits included; FETCH_SIZE doubled for the 16-B/lane loads)"}
+                "note": "fp32 VALU-bound kernel (no MFMA: nothing here is a dense contraction; the schema's bound names are "
+                        "hbm / mfma, this one is the vector ALU); peak = fp32 vector rate at 2.4 GHz (the kernel holds ~2.05 GHz); "
+                        "flops = 1681 px x (11/iteration + 24/set-up), SURVEY 8d: ALGORITHMIC flops, the correlation-cell "
+                        "formulation executes fewer; launch_ms = HIP events around ONE 50k-keypoint launch (landmarks + candidates, "
+                        "nothing beside it) inside whole frame steps, read back once at the end -- the timed steps above run the "
+                        "two sets as two 25k launches on two streams beside the pose chain; " + pmc_note}
         wl.drain()              # single stages from here on: finish what was begun ahead
         a, b = wl.k % 2, (wl.k + 1) % 2
         for name, fn in (("pyramid", lambda: wl.build(b, (wl.k % wl.n_frames) + 1)), ("klt_landmarks+candidates", lambda: wl.track_all(a, b)),

@@ -108,6 +108,8 @@ void vo_or_triangulate(const double* xy0, const double* xy1, const double* poses
                        const double* K, int n, double* X, double* reproj, double* angle, uint8_t* valid) {
     double cam1[12];
     vo_or_camera_matrix(pose1, K, cam1);
+    extern int vo_or_threads;   /* select.c */
+#pragma omp parallel for num_threads(vo_or_threads) schedule(static)
     for (int i = 0; i < n; ++i) {
         double cam0[12], A[16], h[4];
         vo_or_camera_matrix(poses0 + 12 * i, K, cam0);

@@ -9,6 +9,7 @@ All functions work in the INTERNAL image convention (u = fast axis, v = slow axi
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -30,6 +31,44 @@ def lib():
         _LIB.vo_or_angle_deg.restype = C.c_double
         _LIB.vo_or_pyramid_layout.restype = C.c_long
     return _LIB
+
+
+def _bind(path):
+    L = C.CDLL(path)
+    L.vo_or_angle_deg.restype = C.c_double
+    L.vo_or_pyramid_layout.restype = C.c_long
+    return L
+
+
+def use_timing_build():
+    """bench.py's cpu_baseline leg only: switch this process to an optimised build of the same sources -- -O3
+    -march=native compiled on THIS machine (BASELINE.md's flags; needs gcc), else the x86-64-v3 build that travels
+    with the tree, else the -O2 parity build stays.  Returns a description of what is loaded."""
+    global _LIB
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix="vo_oracle_native_"), "libvo_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "native", "OUT=" + out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        _LIB = _bind(out)
+        return "-O3 -march=native, built on this host"
+    except Exception:
+        pass
+    v3 = os.path.join(_HERE, "libvo_oracle_v3.so")
+    if os.path.exists(v3):
+        # the instruction set may be missing on this host: try it in a child first
+        ok = subprocess.call([sys.executable, "-c", "import ctypes,sys; L=ctypes.CDLL(sys.argv[1]); import array; w=(ctypes.c_int32*16)(); L.vo_or_gauss_weights(5, w)", v3],
+                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 0
+        if ok:
+            _LIB = _bind(v3)
+            return "-O3 -march=x86-64-v3 (prebuilt)"
+    lib()
+    return "-O2 (the parity build)"
+
+
+def set_threads(n):
+    """threads of the independent loops in selection and triangulation (the tracker and the pose step take theirs
+    per call); results do not depend on it"""
+    lib().vo_or_set_threads(int(n))
 
 
 class KltOpts(C.Structure):

@@ -14,6 +14,11 @@
 
 static inline int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+/* Threads for the loops whose iterations are independent (response rows, distance filter; geom.c: candidates).
+ * 1 = the serial loops; the results do not depend on it.  Set by bench.py's cpu_baseline leg only. */
+int vo_or_threads = 1;
+void vo_or_set_threads(int n) { vo_or_threads = n > 0 ? n : 1; }
+
 /* N6 integer Gaussian weights; w has filter_size entries */
 void vo_or_gauss_weights(int fs, int32_t* w) {
     int r = fs / 2;
@@ -29,6 +34,7 @@ static void response_mineigen(const uint8_t* img, int nu, int nv, int fs, double
     long n = (long)nu * nv;
     int32_t* a = (int32_t*)malloc(sizeof(int32_t) * n * 3);
     int32_t *b = a + n, *c = b + n;
+#pragma omp parallel for num_threads(vo_or_threads) schedule(static)
     for (int v = 0; v < nv; ++v)
         for (int u = 0; u < nu; ++u) {
             int du = (int)img[(long)v * nu + clampi(u + 1, 0, nu - 1)] - (int)img[(long)v * nu + clampi(u - 1, 0, nu - 1)];
@@ -37,6 +43,7 @@ static void response_mineigen(const uint8_t* img, int nu, int nv, int fs, double
         }
     int64_t* h = (int64_t*)malloc(sizeof(int64_t) * n * 3);
     int64_t *hb = h + n, *hc = hb + n;
+#pragma omp parallel for num_threads(vo_or_threads) schedule(static)
     for (int v = 0; v < nv; ++v)
         for (int u = 0; u < nu; ++u) {
             int64_t sa = 0, sb = 0, sc = 0;
@@ -46,6 +53,7 @@ static void response_mineigen(const uint8_t* img, int nu, int nv, int fs, double
             }
             h[(long)v * nu + u] = sa; hb[(long)v * nu + u] = sb; hc[(long)v * nu + u] = sc;
         }
+#pragma omp parallel for num_threads(vo_or_threads) schedule(static)
     for (int v = 0; v < nv; ++v)
         for (int u = 0; u < nu; ++u) {
             int64_t sa = 0, sb = 0, sc = 0;
@@ -147,6 +155,7 @@ int vo_or_detect_corners(const double* resp, int nu, int nv, double min_quality,
 /* N8, modules/selectCandidateKeypoints.m:23-29 */
 void vo_or_distance_filter(const float* cu, const float* cv, int m, const float* eu, const float* ev,
                            int ne, float mind, uint8_t* keep) {
+#pragma omp parallel for num_threads(vo_or_threads) schedule(dynamic, 64)
     for (int i = 0; i < m; ++i) {
         int k = 1;
         for (int j = 0; j < ne; ++j) {

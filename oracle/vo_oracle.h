@@ -117,6 +117,8 @@ int vo_or_select_uniform(const float* cu, const float* cv, const double* metric,
                          const uint8_t* keep, int m, int n_keep, int nu, int nv,
                          int aspect_u_over_v_is_h_over_w, uint8_t* sel);
 /* full a3 pipeline; out arrays sized `keep`; returns M */
+/* threads for the independent loops of selection and triangulation (default 1; results do not depend on it) */
+void vo_or_set_threads(int n);
 int vo_or_select_candidates(const uint8_t* img, int nu, int nv, const float* eu, const float* ev,
                             int n_exist, float min_distance, double min_quality,
                             int filter_size, int keep, int scorer, double kappa, int col_major,

@@ -17,11 +17,24 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fra
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc sqa SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY
-pmc sqb SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAVES SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_SMEM
+pmc sqb SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAVES SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_BUSY_CYCLES
 pmc tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
 cd $R
 cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
 cp $(find $O/frame_trace -name "*kernel_stats.csv") $O/frame_loop_kernel_stats.csv
 python3 scripts/pmc_summary.py k_lk $(find $O -name "*counter_collection.csv") > $O/k_lk_pmc.txt
+python3 scripts/pmc_json.py 50000 4 $(find $O -name "*counter_collection.csv") > $O/k_lk_pmc.json
+# the tracking launches of the profiled bench by grid size: 50k-keypoint launches (roofline leg, alone on the chip) and
+# 25k-keypoint launches (timed steps: landmarks on the lane stream beside candidates on the ctx stream)
+python3 - "$(find $O/trace -name '*kernel_trace.csv' | head -1)" > $O/k_lk_by_grid.txt <<'PY'
+import csv, sys, collections
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    if "k_lk" in r["Kernel_Name"]:
+        d[int(r.get("Grid_Size", r.get("Grid_Size_X", 0)))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+for g, v in sorted(d.items()):
+    v.sort()
+    print("k_lk grid %8d (%6d keypoints): %5d launches, average %9.1f ns, median %9.1f ns, min %9.1f ns" % (g, g // 64, len(v), sum(v) / len(v), v[len(v) // 2], v[0]))
+PY
 timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 > $O/bench.json
-cat $O/k_lk_pmc.txt; head -8 $O/kernel_stats.csv | cut -c1-160; cat $O/bench.json
+cat $O/k_lk_pmc.txt; cat $O/k_lk_by_grid.txt; head -8 $O/kernel_stats.csv | cut -c1-160; cat $O/bench.json

@@ -158,7 +158,7 @@ class Context:
 
     def counters(self, reset=False):
         out = (C.c_uint64 * 4)()
-        self.call("vo_ctx_read_counters", "vo_stats_gather", out, int(reset))
+        self.call("vo_ctx_read_counters", out, int(reset))
         return list(out)
 
     def timer_start(self):
