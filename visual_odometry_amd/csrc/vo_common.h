@@ -86,9 +86,9 @@ struct vo_sel_work {       // device scratch of the selection pipeline
     double* resp; unsigned long long* maxbits; int32_t* blk_counts; int32_t* blk_offs;
     int32_t* lin; float* lu; float* lv; double* metric; uint8_t* keep; uint8_t* sel;
     int32_t* m0; unsigned long long* cell_key; int32_t* cell_idx; int32_t *klist, *kcell; int cap; int nblk;
-    // uniform grid over the existing points (distance filter)
+    // uniform grid over the detected corners (distance filter)
     float grid_cs; int grid_gu, grid_gv;
-    int32_t *grid_count, *grid_cursor, *grid_offs, *grid_total; float *grid_su, *grid_sv;
+    int32_t *grid_count, *grid_cursor, *grid_offs, *grid_total; float *grid_su, *grid_sv; int32_t* grid_si;
 };
 void vo_select_grid_dims(int nu, int nv, double min_distance, float* cs, int* gu, int* gv);
 int vo_launch_response(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_img, int nu, int nv, int scorer, int fs,

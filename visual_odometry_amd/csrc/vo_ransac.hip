@@ -514,8 +514,11 @@ __device__ __forceinline__ BState shfl_up_state(const BState& x, int d) {
 // One block of BEST_NT threads, each owning a contiguous chunk of hypotheses: local pass, two-level
 // scan of the best-so-far records (wave shuffles, then the 16 wave totals through LDS), then a
 // re-walk of the chunk with the carried-in record that looks for the adaptive stop.
-constexpr int BEST_NT = 256;   // 1024 and 64 were measured too: 8 and 6 us slower per 2000-hypothesis launch
+// BEST_NT = 256 alone on the chip (1024 and 64 were measured too: 8 and 6 us slower per 2000-hypothesis launch);
+// BEST_NT = 64 beside a tracking launch (lane): a four-wave workgroup waits ~180 us for a CU with four free wave
+// slots on four SIMDs at once, a one-wave workgroup takes the first hole.
 constexpr int RANSAC_STAGE = 256;  // hypotheses of the first stage of an adaptive run (a multiple of 64 and of SC_HB)
+template <int BEST_NT>
 __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
     VO_POSE_PRIO();
     __shared__ BState s_wave[BEST_NT / 64];
@@ -553,7 +556,11 @@ __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
     if (lane == 63) s_wave[wid] = inc;
     __syncthreads();
     BState wcarry = none;
-    for (int w = 0; w < wid; ++w) wcarry = combine(a.mode, a.min_inl, wcarry, s_wave[w]);
+    for (int w = 0; w < wid; ++w) {
+        BState sw;   // member-wise out of LDS: a reference to either LDS or registers makes these flat loads
+        sw.h = s_wave[w].h; sw.s = s_wave[w].s; sw.c = s_wave[w].c; sw.q = s_wave[w].q;
+        wcarry = combine(a.mode, a.min_inl, wcarry, sw);
+    }
     BState lcarry = shfl_up_state(inc, 1);
     if (lane == 0) lcarry = none;
     const BState carry = combine(a.mode, a.min_inl, wcarry, lcarry);
@@ -699,7 +706,8 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
         b.cnt = w->cnt; b.cost = w->cost; b.Rt = Rt; b.H = h1; b.M = M; b.mode = o->mode; b.min_inl = o->min_inliers;
         b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 3; b.later_stage = later; b.M_dev = d_M;
         b.bound_out = write_bound ? w->bound : nullptr;
-        hipLaunchKernelGGL(k_best, dim3(1), dim3(BEST_NT), 0, ctx->stream, b);
+        if (ctx->in_lane) hipLaunchKernelGGL(k_best<64>, dim3(1), dim3(64), 0, ctx->stream, b);
+        else hipLaunchKernelGGL(k_best<256>, dim3(1), dim3(256), 0, ctx->stream, b);
     };
     if (!staged) {
         hyp(0, H, false);
@@ -1042,7 +1050,7 @@ int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_
     b.bound_out = nullptr;
     b.cnt = w->cnt; b.cost = w->cost; b.Rt = w->Rt; b.H = H; b.M = M; b.mode = 1; b.min_inl = o->min_inliers;
     b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 8; b.later_stage = 0; b.M_dev = nullptr;
-    hipLaunchKernelGGL(k_best, dim3(1), dim3(BEST_NT), 0, ctx->stream, b);
+    hipLaunchKernelGGL(k_best<256>, dim3(1), dim3(256), 0, ctx->stream, b);
     EInlArgs in;
     in.p0 = d_p0; in.p1 = d_p1; in.sp = sp; in.M = M; in.K = d_K; in.thr = o->max_reproj_err; in.out = (double*)d_out; in.inliers = d_inliers;
     hipLaunchKernelGGL(k_e_inliers, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, in);

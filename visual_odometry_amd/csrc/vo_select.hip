@@ -138,6 +138,25 @@ __global__ __launch_bounds__(256) void k_response(RespArgs a) {
     }
 }
 
+// ---- N8 distance filter, the grid.  keep[i] = no existing point with d2 < thr_d2 (thr_d2 = smallest float whose
+// correctly rounded sqrtf reaches min_distance, computed on the host).  The CORNERS are bucketed into a uniform grid of
+// cell size cs >= min_distance + 1 (counting sort: count -- inside k_detect's write pass --, scan, fill), all of it
+// in the image-only half of the selection, off the frame's critical path; once the existing points are known, one
+// thread per existing point tests the corners of the 3 x 3 cells around its own and clears keep[] of those it is too
+// close to (k_kill).  A pair closer than min_distance differs by less than 1 - 1/cs cells per axis, so the +-1
+// neighbourhood is exhaustive even with the rounding of the float cell computation; clamping out-of-image points
+// into the border cells only moves them towards the cells that must see them.  The verdict is an "any" over pairs,
+// each pair evaluated as the oracle's all-pairs loop evaluates it (corner minus existing point, squares added in the
+// same order): bit-exact, whatever the order of the stores.
+struct GridArgs {
+    float inv_cs; int gu, gv;
+    int32_t *count, *offs, *cursor; float *su, *sv; int32_t* si;   // sorted corner positions and indices
+};
+__device__ __forceinline__ int grid_cell1(float x, float inv_cs, int g) {
+    const float c = floorf(x * inv_cs);
+    return !(c >= 0.0f) ? 0 : (c > (float)(g - 1) ? g - 1 : (int)c); // NaN -> cell 0
+}
+
 // ---- N7 detection.  One block = 1024 consecutive linear indices; pass 0 counts, pass 1 writes.
 constexpr int DT_BLOCK = 1024;
 
@@ -162,7 +181,8 @@ __global__ __launch_bounds__(DT_BLOCK) void k_detect(const double* __restrict__ 
                                                       const unsigned long long* __restrict__ maxbits,
                                                       double min_quality, int pass, int32_t* blk_counts,
                                                       const int32_t* __restrict__ blk_offs, int cap,
-                                                      int32_t* lin, float* lu, float* lv, double* metric) {
+                                                      int32_t* lin, float* lu, float* lv, double* metric,
+                                                      GridArgs g, uint8_t* keep) {
     __shared__ int wave_cnt[DT_BLOCK / 64];
     const long n = (long)nu * nv;
     const long i = (long)blockIdx.x * DT_BLOCK + threadIdx.x;
@@ -192,10 +212,13 @@ __global__ __launch_bounds__(DT_BLOCK) void k_detect(const double* __restrict__ 
     double ou = 0, ov = 0;
     if (cuu < 0) { ou = -0.5 * (rup - rum) / cuu; if (ou > 0.5) ou = 0.5; if (ou < -0.5) ou = -0.5; }
     if (cvv < 0) { ov = -0.5 * (rvp - rvm) / cvv; if (ov > 0.5) ov = 0.5; if (ov < -0.5) ov = -0.5; }
+    const float fu = (float)((double)u + ou), fv = (float)((double)v + ov);
     lin[pos] = (int32_t)i;
-    lu[pos] = (float)((double)u + ou);
-    lv[pos] = (float)((double)v + ov);
+    lu[pos] = fu;
+    lv[pos] = fv;
     metric[pos] = r;
+    keep[pos] = 1;
+    atomicAdd(&g.count[grid_cell1(fv, g.inv_cs, g.gv) * g.gu + grid_cell1(fu, g.inv_cs, g.gu)], 1);
 }
 
 // exclusive scan of the per-block counts (single block), total -> *m0 (clamped to cap)
@@ -235,84 +258,51 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int32_t* __restrict_
     if (t == 0) *m0 = total < cap ? total : cap;
 }
 
-// ---- N8 distance filter: keep[i] = no existing point with d2 < thr_d2 (thr_d2 = smallest float
-// whose correctly rounded sqrtf reaches min_distance, computed on the host).  The existing points
-// are bucketed into a uniform grid of cell size cs >= min_distance + 1 (counting sort: count, scan,
-// fill); a corner then tests the 3 x 3 cells around its own.  A pair closer than min_distance
-// differs by less than 1 - 1/cs cells per axis, so the +-1 neighbourhood is exhaustive even with
-// the rounding of the float cell computation; clamping out-of-image points into the border cells
-// only moves them towards the cells that must see them.  The verdict is an "any", hence independent
-// of the (atomic) order inside a cell: bit-exact against the oracle's all-pairs loop.
-struct GridArgs {
-    const float *eu, *ev; int ne; const int32_t* ne_dev; float inv_cs; int gu, gv;
-    int32_t *count, *offs, *cursor; float *su, *sv;
-};
-__device__ __forceinline__ int grid_cell1(float x, float inv_cs, int g) {
-    const float c = floorf(x * inv_cs);
-    return !(c >= 0.0f) ? 0 : (c > (float)(g - 1) ? g - 1 : (int)c); // NaN -> cell 0
-}
-__global__ __launch_bounds__(256) void k_grid_count(GridArgs a) {
+// second half of the counting sort: corner i goes to its cell's span of the sorted arrays
+__global__ __launch_bounds__(256) void k_grid_fill(const float* __restrict__ cu, const float* __restrict__ cv,
+                                                    const int32_t* __restrict__ m0, GridArgs g) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= (a.ne_dev ? a.ne_dev[0] + a.ne_dev[1] : a.ne)) return;
-    const int c = grid_cell1(a.ev[i], a.inv_cs, a.gv) * a.gu + grid_cell1(a.eu[i], a.inv_cs, a.gu);
-    atomicAdd(&a.count[c], 1);
+    if (i >= *m0) return;
+    const float u = cu[i], v = cv[i];
+    const int c = grid_cell1(v, g.inv_cs, g.gv) * g.gu + grid_cell1(u, g.inv_cs, g.gu);
+    const int pos = g.offs[c] + atomicAdd(&g.cursor[c], 1);
+    g.su[pos] = u; g.sv[pos] = v; g.si[pos] = i;
 }
-__global__ __launch_bounds__(256) void k_grid_fill(GridArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= (a.ne_dev ? a.ne_dev[0] + a.ne_dev[1] : a.ne)) return;
-    const float u = a.eu[i], v = a.ev[i];
-    const int c = grid_cell1(v, a.inv_cs, a.gv) * a.gu + grid_cell1(u, a.inv_cs, a.gu);
-    const int pos = a.offs[c] + atomicAdd(&a.cursor[c], 1);
-    a.su[pos] = u; a.sv[pos] = v;
-}
-// kept corners are also appended to klist (any order: the selectUniform rounds do not depend on it),
-// one global atomic per wave
-__device__ __forceinline__ void append_kept(bool k, int i, int32_t* klist, int32_t* nkeep) {
-    const unsigned long long bal = __ballot(k);
-    if (!bal) return;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == (int)__ffsll((long long)bal) - 1) base = atomicAdd(nkeep, __popcll(bal));
-    base = __shfl(base, (int)__ffsll((long long)bal) - 1, 64);
-    if (k) klist[base + __popcll(bal & ((1ull << lane) - 1ull))] = i;
-}
-__global__ __launch_bounds__(256) void k_distance(const float* __restrict__ cu, const float* __restrict__ cv,
-                                                   const int32_t* __restrict__ m0, GridArgs g, float thr_d2,
-                                                   uint8_t* keep, int32_t* klist, int32_t* nkeep) {
-    const int m = *m0;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    bool k = i < m;
-    if (k) {
-        const float pu = cu[i], pv = cv[i];
-        const int c0u = grid_cell1(pu, g.inv_cs, g.gu), c0v = grid_cell1(pv, g.inv_cs, g.gv);
-        for (int dv = -1; dv <= 1 && k; ++dv) {
-            const int cv_ = c0v + dv;
-            if (cv_ < 0 || cv_ >= g.gv) continue;
-            const int ua = max(c0u - 1, 0), ub = min(c0u + 1, g.gu - 1);
-            // the three cells of one grid row are contiguous in the sorted arrays
-            const int j0 = g.offs[cv_ * g.gu + ua];
-            const int j1 = g.offs[cv_ * g.gu + ub] + g.count[cv_ * g.gu + ub];
-            for (int j = j0; j < j1; ++j) {
-                const float dx = pu - g.su[j], dy = pv - g.sv[j];
-                const float d2 = dx * dx + dy * dy;
-                if (d2 < thr_d2) { k = false; break; }
-            }
+// one thread per existing point and grid row (blockIdx.y = the row of the 3 x 3 neighbourhood): clears keep[] of every
+// corner closer than the threshold.  The launch is a chain of dependent L2 round trips (cell span, positions, index),
+// so the chain is kept short: the span's two ends and the count are loaded together, the span is walked four
+// corners at a time.  One-wave blocks: the launch sits on the frame's critical path right behind a tracking launch
+// that may still hold most of the chip.
+__global__ __launch_bounds__(64) void k_kill(const float* __restrict__ eu, const float* __restrict__ ev, int ne,
+                                              const int32_t* __restrict__ ne_dev, GridArgs g, float thr_d2, uint8_t* keep) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= (ne_dev ? ne_dev[0] + ne_dev[1] : ne)) return;
+    const float pu = eu[i], pv = ev[i];
+    const int c0u = grid_cell1(pu, g.inv_cs, g.gu), c0v = grid_cell1(pv, g.inv_cs, g.gv);
+    const int cv_ = c0v + (int)blockIdx.y - 1;
+    if (cv_ < 0 || cv_ >= g.gv) return;
+    const int ua = max(c0u - 1, 0), ub = min(c0u + 1, g.gu - 1);
+    // the three cells of one grid row are contiguous in the sorted arrays
+    const int j0 = g.offs[cv_ * g.gu + ua];
+    const int j1 = g.offs[cv_ * g.gu + ub] + g.count[cv_ * g.gu + ub];
+    for (int j = j0; j < j1; j += 4) {
+        float du[4], dw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {   // the sorted arrays are padded (arena): reading past the span is harmless
+            du[k] = g.su[j + k] - pu; dw[k] = g.sv[j + k] - pv;
         }
-        keep[i] = k ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d2 = du[k] * du[k] + dw[k] * dw[k];
+            if (j + k < j1 && d2 < thr_d2) keep[g.si[j + k]] = 0;
+        }
     }
-    append_kept(k, i, klist, nkeep);
-}
-__global__ __launch_bounds__(256) void k_keep_all(const int32_t* __restrict__ m0, uint8_t* keep, int32_t* klist, int32_t* nkeep) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool k = i < *m0;
-    if (k) keep[i] = 1;
-    append_kept(k, i, klist, nkeep);
 }
 
 // ---- N8 selectUniform + ordered output.  Single block; cell tables in global scratch.
 struct UniArgs {
     const float *cu, *cv; const double* metric; const int32_t* lin; const uint8_t* keep; uint8_t* sel;
-    const int32_t *m0, *nkeep; int n_keep, nu, nv, u_is_rows;
+    const int32_t* m0; int n_keep, nu, nv, u_is_rows;
     unsigned long long* cell_key; int32_t* cell_idx;
     int32_t *klist, *kcell; // compact list of the kept corners and their cell in the current round
     float *out_u, *out_v; int32_t* out_lin; double* out_metric; int32_t* out_count;
@@ -347,14 +337,170 @@ __device__ __forceinline__ int cell_of(float c, int cells, int n, float inv_n) {
     return cell_exact(c, cells, n, inv_n);
 }
 
+struct UniShared {
+    unsigned long long key[UNI_LDS_CELLS];
+    int idx[UNI_LDS_CELLS];
+    int cnt[UNI_NT / 64];
+    int remaining, selected, round_sel[3], nlist;
+#ifdef UNI_TIMING
+    unsigned long long t0;
+#endif
+};
+
+#ifdef UNI_TIMING
+#define UNI_T(k) do { if (threadIdx.x == 0 && a.out_metric) a.out_metric[200 + (k)] = (double)(wall_clock64() - sh.t0); } while (0)
+#else
+#define UNI_T(k) do {} while (0)
+#endif
+
+// The rounds of selectUniform with every kept corner in a register slot of one of NTA threads and the cell tables in
+// LDS: the rounds touch neither L2 nor HBM.  Called by all NTA threads of the block.
+template <int NTA, int KPT>   // KPT: register slots per thread
+__device__ __forceinline__ void uniform_fast(const UniArgs& a, int t, int m, int nl, unsigned Hu, unsigned Wu, UniShared& sh) {
+    // per corner: coordinates, metric key, and one packed word: index (bits 0-16, corners < 2^17 by
+    // the capacity rule n/4+16 is checked on the host), this round's cell (17-27), selected (31)
+    float fu[KPT], fv[KPT];
+    unsigned long long fk[KPT];
+    unsigned fp[KPT];
+    constexpr unsigned NONE = 0xffffffffu, IDX = 0x1ffffu, CELL_NONE = 0x7ffu;
+    const float inv_nu = 1.0f / (float)a.nu, inv_nv = 1.0f / (float)a.nv;
+    const int kmax = (nl + NTA - 1) / NTA;   // slots in use (uniform)
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int e = t + NTA * k;
+        fp[k] = NONE; fu[k] = fv[k] = 0.0f; fk[k] = 0ull;
+        if (k < kmax && e < nl) {
+            const int i = a.klist[e];
+            fp[k] = (unsigned)i | (CELL_NONE << 17); fu[k] = a.cu[i]; fv[k] = a.cv[i];
+            fk[k] = (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull;
+        }
+    }
+    UNI_T(1);
+    int rounds = 0, selected = 0, remaining = nl;
+    while (selected < a.n_keep && remaining > 0) {
+        // the grid of the round as in k_uniform's general path, in 32-bit arithmetic: want < 2^11 and H, W < 2^19 here
+        const unsigned want = (unsigned)(a.n_keep - selected);
+        unsigned x = (want * Hu) / Wu, h = 0;
+        while ((h + 1) * (h + 1) <= x) ++h;
+        if (h < 1) h = 1;
+        if (h > want) h = want;
+        unsigned w = (h * Wu) / Hu; if (w < 1) w = 1; if (h * w > want) w = want / h;
+        const int cells_u = (int)(a.u_is_rows ? h : w), cells_v = (int)(a.u_is_rows ? w : h);
+        const int nc = cells_u * cells_v;
+        for (int k = t; k < nc; k += NTA) { sh.key[k] = 0ull; sh.idx[k] = 0x7fffffff; }
+        // three counters in turn: the one of the next round is cleared while this round's is summed and the last
+        // round's may still be read by a slow wave
+        if (t == 0) sh.round_sel[(rounds + 1) % 3] = 0;
+        __syncthreads();
+        if (rounds == 0) UNI_T(4);
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) { // phase 1: per-cell maximum metric
+            if (k >= kmax) continue;
+            if (fp[k] == NONE || (fp[k] >> 31)) continue;
+            const int bu = clampi(cell_of(fu[k], cells_u, a.nu, inv_nu), 0, cells_u - 1);
+            const int bv = clampi(cell_of(fv[k], cells_v, a.nv, inv_nv), 0, cells_v - 1);
+            const unsigned cell = (unsigned)(bv * cells_u + bu);
+            fp[k] = (fp[k] & IDX) | (cell << 17);
+            // a plain look first: the table only grows, so a key that does not beat the value seen cannot win,
+            // and after the first few updates almost none does -- thousands of corners on a handful of cells
+            // (late rounds) would otherwise serialise on the same LDS words
+            if (fk[k] > __hip_atomic_load(&sh.key[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMax(&sh.key[cell], fk[k]);
+        }
+        __syncthreads();
+        if (rounds == 0) UNI_T(5);
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) { // phase 2: lowest index among the maxima
+            if (k >= kmax) continue;
+            if (fp[k] == NONE || (fp[k] >> 31)) continue;
+            const unsigned cell = (fp[k] >> 17) & CELL_NONE;
+            if (sh.key[cell] == fk[k]) atomicMin(&sh.idx[cell], (int)(fp[k] & IDX));
+        }
+        __syncthreads();
+        if (rounds == 0) UNI_T(6);
+        int got = 0;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            if (k >= kmax) continue;
+            if (fp[k] == NONE || (fp[k] >> 31)) continue;
+            const unsigned cell = (fp[k] >> 17) & CELL_NONE;
+            if (sh.idx[cell] == (int)(fp[k] & IDX)) { fp[k] |= 0x80000000u; ++got; }
+        }
+        if (got) atomicAdd(&sh.round_sel[rounds % 3], got);
+        __syncthreads();
+        const int rs = sh.round_sel[rounds % 3];
+        selected += rs; remaining -= rs;
+        if (rounds == 0) UNI_T(7);
+        ++rounds;
+    }
+    UNI_T(2);
+#ifdef UNI_TIMING
+    if (t == 0 && a.out_metric) { a.out_metric[210] = rounds; a.out_metric[211] = nl; a.out_metric[212] = m; }
+#endif
+    // output in ascending corner index: the selected corners (<= n_keep <= UNI_LDS_CELLS) go to
+    // LDS, each finds its rank by counting the smaller indices
+#pragma unroll
+    for (int k = 0; k < KPT; ++k)
+        if (k < kmax && fp[k] != NONE && (fp[k] >> 31)) sh.idx[atomicAdd(&sh.nlist, 1)] = (int)(fp[k] & IDX);
+    __syncthreads();
+    const int S = sh.nlist;
+    for (int e = t; e < S; e += NTA) {
+        const int i = sh.idx[e];
+        int pos = 0;
+        for (int j = 0; j < S; ++j) pos += sh.idx[j] < i ? 1 : 0;
+        a.out_u[pos] = a.cu[i]; a.out_v[pos] = a.cv[i];
+        if (a.out_lin) a.out_lin[pos] = a.lin[i];
+        if (a.out_metric) a.out_metric[pos] = a.metric[i];
+    }
+    if (t == 0) *a.out_count = S;
+    UNI_T(3);
+}
+
 __global__ __launch_bounds__(UNI_NT) void k_uniform(UniArgs a) {
-    __shared__ int s_cnt[UNI_NT / 64];
-    __shared__ int s_remaining, s_selected, s_round_sel, s_nlist;
-    __shared__ unsigned long long s_key[UNI_LDS_CELLS];
-    __shared__ int s_idx[UNI_LDS_CELLS];
+    __shared__ UniShared sh;
+    // the frame's critical path runs through this one block while the next frame's image work (side stream) shares
+    // its CU: issue priority over those waves
+    __builtin_amdgcn_s_setprio(3);
+    int* const s_cnt = sh.cnt; int* const s_idx = sh.idx; unsigned long long* const s_key = sh.key;
+    int &s_selected = sh.selected, &s_remaining = sh.remaining, &s_round_sel = sh.round_sel[0], &s_nlist = sh.nlist;
+#ifdef UNI_TIMING
+    if (threadIdx.x == 0) sh.t0 = wall_clock64();
+    __syncthreads();
+#endif
     const int t = threadIdx.x, m = *a.m0;
-    const int nl = *a.nkeep;       // corners that survived the distance filter, compacted by k_distance
-    if (t == 0) { s_selected = 0; s_remaining = nl; s_nlist = 0; }
+    UNI_T(0);
+    // The corners that survived the distance filter, as a compact list in ascending index: 16 flags per thread in one
+    // load, block-wide exclusive scan of the counts.  (k_kill only clears flags: it cannot know which corners are left
+    // before its last store.)
+    int nl = 0;
+    {
+        const int lane = t & 63, wid = t >> 6;
+        for (int start = 0; start < m; start += 16 * UNI_NT) {
+            const int i0 = start + 16 * t;
+            unsigned bits = 0;
+            if (i0 < m) {   // keep[] is 256-byte aligned and padded (arena): the 16 bytes are there
+                const uint4 q = *reinterpret_cast<const uint4*>(a.keep + i0);
+                const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (i0 + k < m && ((w4[k >> 2] >> (8 * (k & 3))) & 0xffu)) bits |= 1u << k;
+            }
+            const int c = __popc(bits);
+            int inc = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+            if (lane == 63) s_cnt[wid] = inc;
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < UNI_NT / 64; ++w2) { const int c2 = s_cnt[w2]; if (w2 < wid) before += c2; total += c2; }
+            int pos = nl + before + inc - c;
+            while (bits) { const int k = __ffs((int)bits) - 1; bits &= bits - 1u; a.klist[pos++] = i0 + k; }
+            nl += total;
+            __syncthreads();
+        }
+    }
+    if (t == 0) { s_selected = 0; s_remaining = nl; s_nlist = 0; sh.round_sel[0] = 0; }
+    __threadfence_block();
     __syncthreads();
     const long H = a.u_is_rows ? a.nu : a.nv, W = a.u_is_rows ? a.nv : a.nu;
     const float inv_nu = 1.0f / (float)a.nu, inv_nv = 1.0f / (float)a.nv;
@@ -363,86 +509,12 @@ __global__ __launch_bounds__(UNI_NT) void k_uniform(UniArgs a) {
     // asking for at least as many points as survive selects them all (bootstrap: selectUniform over every
     // detected corner, modules/bootstrap.m:36-38) -- the rounds would end there too
     const bool all = a.n_keep >= nl;
-    const bool fast = !all && nl <= UNI_NT * UNI_KPT && a.n_keep <= UNI_LDS_CELLS - 1 && m <= 0x1ffff;
+    const bool fast = !all && nl <= UNI_NT * UNI_KPT && a.n_keep <= UNI_LDS_CELLS - 1 && m <= 0x1ffff && H < (1 << 19) && W < (1 << 19);
     if (fast) {
-        // per corner: coordinates, metric key, and one packed word: index (bits 0-16, corners < 2^17 by
-        // the capacity rule n/4+16 is checked on the host), this round's cell (17-27), selected (31)
-        float fu[UNI_KPT], fv[UNI_KPT];
-        unsigned long long fk[UNI_KPT];
-        unsigned fp[UNI_KPT];
-        constexpr unsigned NONE = 0xffffffffu, IDX = 0x1ffffu, CELL_NONE = 0x7ffu;
-#pragma unroll
-        for (int k = 0; k < UNI_KPT; ++k) {
-            const int e = t + UNI_NT * k;
-            fp[k] = NONE; fu[k] = fv[k] = 0.0f; fk[k] = 0ull;
-            if (e < nl) {
-                const int i = a.klist[e];
-                fp[k] = (unsigned)i | (CELL_NONE << 17); fu[k] = a.cu[i]; fv[k] = a.cv[i];
-                fk[k] = (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull;
-            }
-        }
-        while (true) {
-            const int selected = s_selected, remaining = s_remaining;
-            if (!(selected < a.n_keep && remaining > 0)) break;
-            const long want = a.n_keep - selected;
-            long x = (want * H) / W, h = 0;
-            while ((h + 1) * (h + 1) <= x) ++h;
-            if (h < 1) h = 1;
-            if (h > want) h = want;
-            long w = (h * W) / H; if (w < 1) w = 1; if (h * w > want) w = want / h;
-            const int cells_u = (int)(a.u_is_rows ? h : w), cells_v = (int)(a.u_is_rows ? w : h);
-            const int nc = cells_u * cells_v;
-            for (int k = t; k < nc; k += UNI_NT) { s_key[k] = 0ull; s_idx[k] = 0x7fffffff; }
-            if (t == 0) s_round_sel = 0;
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < UNI_KPT; ++k) { // phase 1: per-cell maximum metric
-                if (fp[k] == NONE || (fp[k] >> 31)) continue;
-                const int bu = clampi(cell_of(fu[k], cells_u, a.nu, inv_nu), 0, cells_u - 1);
-                const int bv = clampi(cell_of(fv[k], cells_v, a.nv, inv_nv), 0, cells_v - 1);
-                const unsigned cell = (unsigned)(bv * cells_u + bu);
-                fp[k] = (fp[k] & IDX) | (cell << 17);
-                // a plain look first: the table only grows, so a key that does not beat the value seen cannot win,
-                // and after the first few updates almost none does -- thousands of corners on a handful of cells
-                // (late rounds) would otherwise serialise on the same LDS words
-                if (fk[k] > *(volatile unsigned long long*)&s_key[cell]) atomicMax(&s_key[cell], fk[k]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < UNI_KPT; ++k) { // phase 2: lowest index among the maxima
-                if (fp[k] == NONE || (fp[k] >> 31)) continue;
-                const unsigned cell = (fp[k] >> 17) & CELL_NONE;
-                if (s_key[cell] == fk[k]) atomicMin(&s_idx[cell], (int)(fp[k] & IDX));
-            }
-            __syncthreads();
-            int got = 0;
-#pragma unroll
-            for (int k = 0; k < UNI_KPT; ++k) {
-                if (fp[k] == NONE || (fp[k] >> 31)) continue;
-                const unsigned cell = (fp[k] >> 17) & CELL_NONE;
-                if (s_idx[cell] == (int)(fp[k] & IDX)) { fp[k] |= 0x80000000u; ++got; }
-            }
-            if (got) atomicAdd(&s_round_sel, got);
-            __syncthreads();
-            if (t == 0) { s_selected += s_round_sel; s_remaining -= s_round_sel; }
-            __syncthreads();
-        }
-        // output in ascending corner index: the selected corners (<= n_keep <= UNI_LDS_CELLS) go to
-        // LDS, each finds its rank by counting the smaller indices
-#pragma unroll
-        for (int k = 0; k < UNI_KPT; ++k)
-            if (fp[k] != NONE && (fp[k] >> 31)) s_idx[atomicAdd(&s_nlist, 1)] = (int)(fp[k] & IDX);
-        __syncthreads();
-        const int S = s_nlist;
-        for (int e = t; e < S; e += UNI_NT) {
-            const int i = s_idx[e];
-            int pos = 0;
-            for (int j = 0; j < S; ++j) pos += s_idx[j] < i ? 1 : 0;
-            a.out_u[pos] = a.cu[i]; a.out_v[pos] = a.cv[i];
-            if (a.out_lin) a.out_lin[pos] = a.lin[i];
-            if (a.out_metric) a.out_metric[pos] = a.metric[i];
-        }
-        if (t == 0) *a.out_count = S;
+        // (fewer waves with more slots each were measured for short lists -- 256 threads x 6 slots at 1300 corners:
+        // a round is bound by the dependent instruction chain of a slot, ~500 cycles for a wave alone on its SIMD, and
+        // four waves a SIMD hide most of that for each other: 2.4 us a round with 1024 threads, 2.9 us with 256)
+        uniform_fast<UNI_NT, UNI_KPT>(a, t, m, nl, (unsigned)H, (unsigned)W, sh);
         return;
     }
     if (all && nl <= UNI_LDS_CELLS) {
@@ -492,7 +564,7 @@ __global__ __launch_bounds__(UNI_NT) void k_uniform(UniArgs a) {
             const int cell = bv * cells_u + bu;
             a.kcell[e] = cell;
             const unsigned long long key = (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull;
-            if (lds) { if (key > *(volatile unsigned long long*)&s_key[cell]) atomicMax(&s_key[cell], key); }
+            if (lds) { if (key > __hip_atomic_load(&s_key[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMax(&s_key[cell], key); }
             else if (key > __hip_atomic_load(&a.cell_key[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&a.cell_key[cell], key);
         }
         __threadfence_block();
@@ -657,6 +729,13 @@ static float d2_threshold(float d) {
     return x;
 }
 
+static GridArgs grid_args(const vo_sel_work* w) {
+    GridArgs g;
+    g.inv_cs = 1.0f / w->grid_cs; g.gu = w->grid_gu; g.gv = w->grid_gv;
+    g.count = w->grid_count; g.offs = w->grid_offs; g.cursor = w->grid_cursor; g.su = w->grid_su; g.sv = w->grid_sv; g.si = w->grid_si;
+    return g;
+}
+
 void vo_select_grid_dims(int nu, int nv, double min_distance, float* cs, int* gu, int* gv) {
     float c = (float)min_distance + 1.0f;
     if (!(c >= 2.0f)) c = 2.0f;
@@ -668,22 +747,25 @@ void vo_select_grid_dims(int nu, int nv, double min_distance, float* cs, int* gu
 int vo_launch_select_detect(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_img, int nu, int nv, const vo_sel_opts* o,
                             vo_sel_work* w) {
     if (o->keep < 0) { ctx->last_error = "select: negative count"; return VO_ERR_BAD_ARG; }
+    // the corner grid's tables (count + cursor) start at zero.  Rounded up to 16 bytes (one fill kernel instead of
+    // two; the arena pads every table by 256 bytes).
+    const size_t grid_bytes = (sizeof(int32_t) * 2 * (size_t)w->grid_gu * w->grid_gv + 15) & ~(size_t)15;
+    VO_HIP_CHECK(ctx, hipMemsetAsync(w->grid_count, 0, grid_bytes, stream));
     int rc = vo_launch_response(ctx, stream, d_img, nu, nv, o->scorer, o->filter_size, o->kappa, w->resp, w->maxbits);
     if (rc) return rc;
     const long n = (long)nu * nv;
     const int nblk = (int)((n + DT_BLOCK - 1) / DT_BLOCK);
     if (nblk > w->nblk) { ctx->last_error = "select: scratch too small"; return VO_ERR_BAD_ARG; }
+    const GridArgs g = grid_args(w);
     hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, stream, w->resp, nu, nv, w->maxbits,
-                       o->min_quality, 0, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric);
+                       o->min_quality, 0, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric, g, w->keep);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, w->blk_counts, nblk, w->blk_offs, w->m0, w->cap);
     hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, stream, w->resp, nu, nv, w->maxbits,
-                       o->min_quality, 1, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric);
-    VO_HIP_CHECK(ctx, hipMemsetAsync(w->m0 + 1, 0, sizeof(int32_t), stream)); // number of kept corners
-    // the distance filter's grid tables (count + cursor) start at zero; nothing but the grid size is needed for
-    // that, so it is done here, where the two-call forms run beside other work.  Rounded up to 16 bytes (one
-    // fill kernel instead of two; the arena pads every table by 256 bytes).
-    const size_t grid_bytes = (sizeof(int32_t) * 2 * (size_t)w->grid_gu * w->grid_gv + 15) & ~(size_t)15;
-    VO_HIP_CHECK(ctx, hipMemsetAsync(w->grid_count, 0, grid_bytes, stream));
+                       o->min_quality, 1, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric, g, w->keep);
+    // the corner grid of the distance filter: counted by the write pass above, scanned and filled here
+    const int ncell = g.gu * g.gv;
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, g.count, ncell, g.offs, w->grid_total, 0x7fffffff);
+    hipLaunchKernelGGL(k_grid_fill, dim3((w->cap + 255) / 256), dim3(256), 0, stream, w->lu, w->lv, w->m0, g);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }
@@ -693,24 +775,11 @@ int vo_launch_select_filter(vo_ctx* ctx, hipStream_t stream, int nu, int nv, int
                             float* d_out_u, float* d_out_v, int32_t* d_out_lin, double* d_out_metric,
                             int32_t* d_out_count) {
     if (o->keep < 0 || n_exist < 0) { ctx->last_error = "select: negative count"; return VO_ERR_BAD_ARG; }
-    const int dblk = (w->cap + 255) / 256;
     const float thr_d2 = d2_threshold((float)o->min_distance);
-    if (n_exist == 0 || !(thr_d2 > 0.0f)) {
-        hipLaunchKernelGGL(k_keep_all, dim3(dblk), dim3(256), 0, stream, w->m0, w->keep, w->klist, w->m0 + 1);
-    } else {
-        GridArgs g;
-        g.eu = d_eu; g.ev = d_ev; g.ne = n_exist; g.ne_dev = ne_dev; g.inv_cs = 1.0f / w->grid_cs; g.gu = w->grid_gu; g.gv = w->grid_gv;
-        g.count = w->grid_count; g.offs = w->grid_offs; g.cursor = w->grid_cursor; g.su = w->grid_su; g.sv = w->grid_sv;
-        const int ncell = g.gu * g.gv;
-        // count + cursor were zeroed by the detect half (vo_launch_select_detect), off this stream's critical path
-        const int eblk = (n_exist + 255) / 256;
-        hipLaunchKernelGGL(k_grid_count, dim3(eblk), dim3(256), 0, stream, g);
-        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, g.count, ncell, g.offs, w->grid_total, 0x7fffffff);
-        hipLaunchKernelGGL(k_grid_fill, dim3(eblk), dim3(256), 0, stream, g);
-        hipLaunchKernelGGL(k_distance, dim3(dblk), dim3(256), 0, stream, w->lu, w->lv, w->m0, g, thr_d2, w->keep, w->klist, w->m0 + 1);
-    }
+    if (n_exist > 0 && thr_d2 > 0.0f)   // otherwise every corner keeps the flag the detect half gave it
+        hipLaunchKernelGGL(k_kill, dim3((n_exist + 63) / 64, 3), dim3(64), 0, stream, d_eu, d_ev, n_exist, ne_dev, grid_args(w), thr_d2, w->keep);
     UniArgs a;
-    a.cu = w->lu; a.cv = w->lv; a.metric = w->metric; a.lin = w->lin; a.keep = w->keep; a.sel = w->sel; a.m0 = w->m0; a.nkeep = w->m0 + 1;
+    a.cu = w->lu; a.cv = w->lv; a.metric = w->metric; a.lin = w->lin; a.keep = w->keep; a.sel = w->sel; a.m0 = w->m0;
     a.n_keep = o->keep; a.nu = nu; a.nv = nv; a.u_is_rows = u_is_rows;
     a.cell_key = w->cell_key; a.cell_idx = w->cell_idx; a.klist = w->klist; a.kcell = w->kcell;
     a.out_u = d_out_u; a.out_v = d_out_v; a.out_lin = d_out_lin; a.out_metric = d_out_metric; a.out_count = d_out_count;
