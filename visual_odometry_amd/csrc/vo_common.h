@@ -92,7 +92,8 @@ struct vo_sel_work {       // device scratch of the selection pipeline
 };
 void vo_select_grid_dims(int nu, int nv, double min_distance, float* cs, int* gu, int* gv);
 int vo_launch_response(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_img, int nu, int nv, int scorer, int fs,
-                       double kappa, double* d_resp, unsigned long long* d_maxbits);
+                       double kappa, double* d_resp, unsigned long long* d_maxbits, unsigned* d_zero = nullptr,
+                       long zero_words = 0);   // d_zero: a word range cleared in the launch that clears *d_maxbits
 // selection in two phases: detect needs the image only (response, threshold, regional maxima, corner list);
 // filter needs the existing points (distance filter, selectUniform).  ne_dev (optional): the number of
 // existing points is ne_dev[0] + ne_dev[1] read on the device, n_exist is then only its upper bound.

@@ -27,6 +27,15 @@ struct RespArgs {
     unsigned long long* maxbits;
 };
 
+// zeroes the running maximum and (optionally) a word range -- the corner grid's tables -- in one launch.  A kernel of
+// our own, not hipMemsetAsync: the runtime's fill kernels were seen to hold back the dispatch of kernels on the
+// ctx's OTHER streams until they had finished (the frame's tail waited ~10-20 us for the side stream's memsets).
+__global__ __launch_bounds__(256) void k_sel_zero(unsigned long long* maxbits, unsigned* p, long nwords) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && maxbits) *maxbits = 0ull;
+    if (i < nwords) p[i] = 0u;
+}
+
 // One block = one RS_TU x RS_TV tile.  LDS: uint8 tile with halo r+1; int32 products on the tile
 // with halo r; int32 horizontal sums, int64 vertical sums.  MINEIGEN uses replicate borders at every stage (N6), HARRIS
 // only produces values where the whole support is inside the image (old/harris.m 'valid').
@@ -134,7 +143,121 @@ __global__ __launch_bounds__(256) void k_response(RespArgs a) {
             unsigned long long o = __shfl_xor(bits, s, 64);
             bits = o > bits ? o : bits;
         }
-        if ((tid & 63) == 0 && bits) atomicMax(a.maxbits, bits);
+        // a plain look first: the word only grows, and after the first few tiles almost no wave beats it -- two
+        // thousand same-address atomics in a row were most of this kernel's time
+        if ((threadIdx.x & 63) == 0 && bits > __hip_atomic_load(a.maxbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(a.maxbits, bits);
+    }
+}
+
+// The min-eigen response with the filter radius known at compile time (R = 2 is the reference's FilterSize 5,
+// modules/VisualOdometry.m:332): the same three LDS stages and the same integer / double arithmetic as k_response,
+// with every tap loop unrolled, the weights in registers, no index division, and the border clamps only in the tiles
+// that touch the image border (EDGE).  Thread (tx, ty) owns column tx of rows ty, ty + 4, ...
+template <int R, bool EDGE>
+__device__ __forceinline__ void response_me_tile(const RespArgs& a, unsigned char* smem, double& bmax) {
+    constexpr int SW = RS_TU + 2 * R + 2, SH = RS_TV + 2 * R + 2, PW = RS_TU + 2 * R, PH = RS_TV + 2 * R;
+    constexpr int SWP = (SW + 3) & ~3;
+    uint8_t* S = smem;
+    int32_t* pa = (int32_t*)(smem + ((SWP * SH + 15) & ~15));
+    int32_t* pb = pa + PW * PH;
+    int32_t* pc = pb + PW * PH;
+    int32_t* ha = pc + PW * PH;
+    int32_t* hb = ha + RS_TU * PH;
+    int32_t* hc = hb + RS_TU * PH;
+    const int nu = a.nu, nv = a.nv;
+    const int u0 = blockIdx.x * RS_TU, v0 = blockIdx.y * RS_TV;
+    const int su0 = u0 - R - 1, sv0 = v0 - R - 1;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    int32_t w[2 * R + 1];
+#pragma unroll
+    for (int k = 0; k <= 2 * R; ++k) w[k] = a.w[k];
+    // stage: image bytes with halo R + 1 (clamped into the image in edge tiles)
+    for (int y = ty; y < SH; y += 4) {
+        const int gy = EDGE ? clampi(sv0 + y, 0, nv - 1) : sv0 + y;
+        const uint8_t* row = a.img + (long)gy * nu;
+        S[y * SWP + tx] = row[EDGE ? clampi(su0 + tx, 0, nu - 1) : su0 + tx];
+        if (tx < SW - 64) S[y * SWP + 64 + tx] = row[EDGE ? clampi(su0 + 64 + tx, 0, nu - 1) : su0 + 64 + tx];
+    }
+    __syncthreads();
+    // gradient products at (u0 - R + x, v0 - R + y); S index of image (cu, cv) is (cv - sv0, cu - su0)
+    auto products = [&](int x, int y) {
+        int du, dv;
+        if (EDGE) {
+            const int cu = clampi(u0 - R + x, 0, nu - 1), cv = clampi(v0 - R + y, 0, nv - 1);
+            const int sy = cv - sv0, sx = cu - su0;
+            du = (int)S[sy * SWP + (clampi(cu + 1, 0, nu - 1) - su0)] - (int)S[sy * SWP + (clampi(cu - 1, 0, nu - 1) - su0)];
+            dv = (int)S[(clampi(cv + 1, 0, nv - 1) - sv0) * SWP + sx] - (int)S[(clampi(cv - 1, 0, nv - 1) - sv0) * SWP + sx];
+        } else {
+            const int sy = y + 1, sx = x + 1;
+            du = (int)S[sy * SWP + sx + 1] - (int)S[sy * SWP + sx - 1];
+            dv = (int)S[(sy + 1) * SWP + sx] - (int)S[(sy - 1) * SWP + sx];
+        }
+        pa[y * PW + x] = du * du; pb[y * PW + x] = du * dv; pc[y * PW + x] = dv * dv;
+    };
+    for (int y = ty; y < PH; y += 4) {
+        products(tx, y);
+        if (tx < PW - 64) products(64 + tx, y);
+    }
+    __syncthreads();
+    // horizontal pass: the column indices do not depend on the row
+    int xx[2 * R + 1];
+#pragma unroll
+    for (int k = 0; k <= 2 * R; ++k)
+        xx[k] = EDGE ? clampi(clampi(u0 + tx + k - R, 0, nu - 1) - (u0 - R), 0, PW - 1) : tx + k;
+    for (int y = ty; y < PH; y += 4) {
+        int32_t sa = 0, sb = 0, sc = 0;
+#pragma unroll
+        for (int k = 0; k <= 2 * R; ++k) {
+            sa += w[k] * pa[y * PW + xx[k]]; sb += w[k] * pb[y * PW + xx[k]]; sc += w[k] * pc[y * PW + xx[k]];
+        }
+        ha[y * RS_TU + tx] = sa; hb[y * RS_TU + tx] = sb; hc[y * RS_TU + tx] = sc;
+    }
+    __syncthreads();
+    const int u = u0 + tx;
+#pragma unroll
+    for (int j = 0; j < RS_TV / 4; ++j) {
+        const int y = ty + 4 * j, v = v0 + y;
+        if (EDGE && (u >= nu || v >= nv)) continue;
+        long long sa = 0, sb = 0, sc = 0;
+#pragma unroll
+        for (int k = 0; k <= 2 * R; ++k) {
+            const int yy = EDGE ? clampi(clampi(v + k - R, 0, nv - 1) - (v0 - R), 0, PH - 1) : y + k;
+            sa += (long long)w[k] * ha[yy * RS_TU + tx]; sb += (long long)w[k] * hb[yy * RS_TU + tx];
+            sc += (long long)w[k] * hc[yy * RS_TU + tx];
+        }
+        const double A = (double)sa, B = (double)sb, C = (double)sc;
+        const double dif = A - C;
+        const double rad = dif * dif + 4.0 * (B * B);
+        double lam = 0.5 * ((A + C) - sqrt(rad));
+        if (lam < 0.0) lam = 0.0;
+        const double out = lam * (1.0 / 67108864.0);
+        a.resp[(long)v * nu + u] = out;
+        if (out > bmax) bmax = out;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_response_me(RespArgs a) {
+    constexpr int SW = RS_TU + 2 * R + 2, SH = RS_TV + 2 * R + 2, PW = RS_TU + 2 * R, PH = RS_TV + 2 * R;
+    constexpr int SWP = (SW + 3) & ~3;
+    __shared__ __align__(16) unsigned char smem[((SWP * SH + 15) & ~15) + 4 * (3 * PW * PH + 3 * RS_TU * PH)];
+    const int u0 = blockIdx.x * RS_TU, v0 = blockIdx.y * RS_TV;
+    const bool edge = u0 - R - 1 < 0 || v0 - R - 1 < 0 || u0 + RS_TU + R + 1 > a.nu || v0 + RS_TV + R + 1 > a.nv;
+    double bmax = 0.0;
+    if (edge) response_me_tile<R, true>(a, smem, bmax);
+    else response_me_tile<R, false>(a, smem, bmax);
+    if (a.maxbits) {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(bmax);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            unsigned long long o = __shfl_xor(bits, s, 64);
+            bits = o > bits ? o : bits;
+        }
+        // a plain look first: the word only grows, and after the first few tiles almost no wave beats it -- two
+        // thousand same-address atomics in a row were most of this kernel's time
+        if ((threadIdx.x & 63) == 0 && bits > __hip_atomic_load(a.maxbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(a.maxbits, bits);
     }
 }
 
@@ -697,7 +820,7 @@ static void gauss_weights_host(int fs, int32_t* w) { // N6, identical to oracle/
 }
 
 int vo_launch_response(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_img, int nu, int nv, int scorer, int fs,
-                       double kappa, double* d_resp, unsigned long long* d_maxbits) {
+                       double kappa, double* d_resp, unsigned long long* d_maxbits, unsigned* d_zero, long zero_words) {
     if (fs < 1 || fs > 15 || !(fs & 1)) { ctx->last_error = "select: filter_size must be odd in [1,15]"; return VO_ERR_BAD_ARG; }
     if (scorer != VO_SCORER_MINEIGEN && scorer != VO_SCORER_HARRIS) { ctx->last_error = "select: unknown scorer"; return VO_ERR_BAD_ARG; }
     if (nu < 3 || nv < 3) { ctx->last_error = "select: image smaller than 3x3"; return VO_ERR_BAD_ARG; }
@@ -709,11 +832,17 @@ int vo_launch_response(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_img, in
     const int r = a.r;
     const int SW = RS_TU + 2 * r + 2, SH = RS_TV + 2 * r + 2, PW = RS_TU + 2 * r, PH = RS_TV + 2 * r;
     size_t lds = ((size_t)(SW * SH + 15) & ~(size_t)15) + sizeof(int32_t) * (3 * (size_t)PW * PH + 3 * (size_t)RS_TU * PH);
-    if (d_maxbits) VO_HIP_CHECK(ctx, hipMemsetAsync(d_maxbits, 0, sizeof(unsigned long long), stream));
+    if (d_maxbits || zero_words > 0)
+        hipLaunchKernelGGL(k_sel_zero, dim3((unsigned)((std::max(zero_words, 1L) + 255) / 256)), dim3(256), 0, stream, d_maxbits, d_zero, zero_words);
     dim3 grid((nu + RS_TU - 1) / RS_TU, (nv + RS_TV - 1) / RS_TV);
     if (!ctx->resp_attr_set) {
         VO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)k_response, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         ctx->resp_attr_set = true;
+    }
+    if (scorer == VO_SCORER_MINEIGEN && r == 2) {   // the reference's configuration: the unrolled kernel
+        hipLaunchKernelGGL(k_response_me<2>, grid, dim3(256), 0, stream, a);
+        VO_HIP_CHECK(ctx, hipGetLastError());
+        return VO_OK;
     }
     hipLaunchKernelGGL(k_response, grid, dim3(256), lds, stream, a);
     VO_HIP_CHECK(ctx, hipGetLastError());
@@ -747,11 +876,10 @@ void vo_select_grid_dims(int nu, int nv, double min_distance, float* cs, int* gu
 int vo_launch_select_detect(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_img, int nu, int nv, const vo_sel_opts* o,
                             vo_sel_work* w) {
     if (o->keep < 0) { ctx->last_error = "select: negative count"; return VO_ERR_BAD_ARG; }
-    // the corner grid's tables (count + cursor) start at zero.  Rounded up to 16 bytes (one fill kernel instead of
-    // two; the arena pads every table by 256 bytes).
-    const size_t grid_bytes = (sizeof(int32_t) * 2 * (size_t)w->grid_gu * w->grid_gv + 15) & ~(size_t)15;
-    VO_HIP_CHECK(ctx, hipMemsetAsync(w->grid_count, 0, grid_bytes, stream));
-    int rc = vo_launch_response(ctx, stream, d_img, nu, nv, o->scorer, o->filter_size, o->kappa, w->resp, w->maxbits);
+    // the corner grid's tables (count + cursor) start at zero: cleared by the launch that clears the running maximum
+    const long grid_words = 2 * (long)w->grid_gu * w->grid_gv;
+    int rc = vo_launch_response(ctx, stream, d_img, nu, nv, o->scorer, o->filter_size, o->kappa, w->resp, w->maxbits,
+                                (unsigned*)w->grid_count, grid_words);
     if (rc) return rc;
     const long n = (long)nu * nv;
     const int nblk = (int)((n + DT_BLOCK - 1) / DT_BLOCK);
