@@ -330,7 +330,9 @@ struct ScoreArgs {
     int h0;                 // contiguous form: first hypothesis of this launch (block b scores hypotheses h0 + 2b, h0 + 2b + 1)
     const int32_t* list;    // list form (non-null): pose ids 4h + s, eight per block, *list_n of them
     const int32_t* list_n;
-    int q0, q1;             // the launch scores points [M q0 / 8, M q1 / 8); blockIdx.y takes one of gridDim.y equal parts
+    int q0, q1;             // the launch scores points [M Q0 / 64, M Q1 / 64); blockIdx.y takes one of gridDim.y equal parts.
+                            // qdev null: Q = q.  qdev non-null: q indexes {0, qdev[0], qdev[1], 64} (sieve_mark)
+    const int32_t* qdev;    // the two sieve marks of a staged run, chosen on the device by the first stage's k_best
     const int32_t* stopped; // as in HypArgs
     const int32_t* M_dev;   // as in HypArgs
 };
@@ -342,6 +344,10 @@ struct ScoreArgs {
 // workgroups (vo_ctx_lane_*), such a block fits the hole any finished tracking wave leaves; a 256-thread block had to
 // wait for four holes on one CU at once and starved (as did the runtime's memset kernel: hence k_zero).
 constexpr int SC_NT = 64;
+__device__ __forceinline__ int sieve_mark(const int32_t* qdev, int q) {
+    if (!qdev) return q;
+    return q <= 0 ? 0 : (q == 1 ? qdev[0] : (q == 2 ? qdev[1] : 64));
+}
 __global__ __launch_bounds__(SC_NT) void k_score(ScoreArgs a) {
     VO_POSE_PRIO();
     __shared__ double sRt[SC_NS * 12];
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(SC_NT) void k_score(ScoreArgs a) {
         sRt[k] = pid >= 0 ? proj_elem(a.Rt + 12 * (long)pid, a.K, e >> 2, e & 3) : 0.0;
     }
     __syncthreads();
-    const long r0 = (long)a.M * a.q0 / 8, r1 = (long)a.M * a.q1 / 8;
+    const long r0 = (long)a.M * sieve_mark(a.qdev, a.q0) / 64, r1 = (long)a.M * sieve_mark(a.qdev, a.q1) / 64;
     const long per = (r1 - r0 + gridDim.y - 1) / gridDim.y;
     const int c0 = (int)(r0 + per * blockIdx.y), c1 = (int)min(r0 + per * (blockIdx.y + 1), r1);
     const double thr2 = a.thr2;
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(64) void k_zero(unsigned* p, long nwords) {
     if (i < nwords) p[i] = 0u;
 }
 
-// Which poses of the hypotheses [h0, H) can still become the record after `seen` eighths of the points?
+// Which poses of the hypotheses [h0, H) can still become the record after the points up to sieve mark `seen`?
 // bound[0] = the cost (mode 1) or the inlier count (mode 0) of the best record among the hypotheses BEFORE h0, written
 // by the first stage's k_best.  After n points a pose's final cost is at least its cost so far, its final count at most
 // its count so far + (M - n).  A later hypothesis replaces the record only by strict improvement
@@ -444,6 +450,7 @@ __global__ __launch_bounds__(64) void k_zero(unsigned* p, long nwords) {
 struct SurvArgs {
     const int32_t* cnt; const unsigned long long* cost; const unsigned long long* bound; int h0, H, M, mode, seen;
     const int32_t* in; const int32_t* in_n; int32_t* list; int32_t* list_n; const int32_t* stopped; const int32_t* M_dev;
+    const int32_t* qdev;    // as in ScoreArgs: `seen` indexes the sieve marks
 };
 __global__ __launch_bounds__(64) void k_survivors(SurvArgs a) {
     VO_POSE_PRIO();
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(64) void k_survivors(SurvArgs a) {
     if (a.in) { if (k >= *a.in_n) return; pid = a.in[k]; }
     else { pid = 4 * a.h0 + k; if (pid >= 4 * a.H) return; }
     const unsigned long long bound = a.bound[0];
-    const long seen = (long)a.M * a.seen / 8;      // where k_score's ranges so far end
+    const long seen = (long)a.M * sieve_mark(a.qdev, a.seen) / 64;      // where k_score's ranges so far end
     const bool alive = a.mode == 1 ? (a.cost[pid] < bound)
                                    : ((unsigned long long)((long)a.cnt[pid] + ((long)a.M - seen)) > bound);
     if (alive) a.list[atomicAdd(a.list_n, 1)] = pid;
@@ -498,6 +505,8 @@ struct BestArgs {
     int later_stage;                // 1: an earlier stage ran on a prefix; keep its record if it reached the stop
     const int32_t* M_dev;           // as in HypArgs; fewer than 4 points: status 1 and the identity
     unsigned long long* bound_out;  // non-null (first stage): the record's cost / count for k_score's early out
+    int32_t* sieve_out;             // with bound_out: the two sieve marks (64ths of the points), see below
+    unsigned long long qthr;        // an outlier's cost term in the fixed point of `cost`
 };
 
 __device__ __forceinline__ BState combine(int mode, int min_inl, const BState& earlier, const BState& later) {
@@ -601,8 +610,23 @@ __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
             info[0] = 2;
         }
         info[1] = fin.h; info[2] = fin.s; info[3] = used; info[4] = 0;
-        if (a.bound_out)   // no record yet: a bound no pose can fail
+        if (a.bound_out) {  // no record yet: a bound no pose can fail
             a.bound_out[0] = fin.h >= 0 ? (a.mode == 1 ? fin.q : (unsigned long long)fin.c) : (a.mode == 1 ? ~0ull : 0ull);
+            // Where to sieve.  A pose without inliers falls behind the record once rho = (record's cost) / (cost of
+            // M outliers) of the points are seen (count mode: rho = 1 - record's count / M); most of the second
+            // stage's poses are of that kind, so the first mark sits just behind rho -- every 64th of the points
+            // before it is work on poses that cannot win yet cannot be dropped, every 64th behind it is work on poses
+            // that could have been dropped.  The second mark halves what is left.  Any marks give the same record
+            // (k_survivors' argument does not depend on them); these only decide how much is scored.
+            double rho = 1.0;
+            if (fin.h >= 0)
+                rho = a.mode == 1 ? (double)fin.q / ((double)a.M * (double)a.qthr) : 1.0 - (double)fin.c / (double)a.M;
+            int f1 = (int)(rho * 68.0) + 2;          // 64 rho, 6 % further, rounded up and one more
+            f1 = f1 < 4 ? 4 : (f1 > 56 ? 56 : f1);
+            const int rest = (64 - f1) / 2;
+            a.sieve_out[0] = f1;
+            a.sieve_out[1] = f1 + (rest < 2 ? 2 : rest);
+        }
         info[5] = gstop == 0x7fffffff ? 0 : 1;   // the adaptive stop was reached inside these H hypotheses
     }
 }
@@ -668,9 +692,10 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
     // Two stages when the run is long.  The first generates, fully scores and scans the first RANSAC_STAGE hypotheses.
     // With the adaptive stop (confidence > 0) the sequential semantics usually end among them -- the record at the
     // stop depends on the hypotheses before it only -- and the second stage returns at once.  Otherwise the second
-    // stage scores the rest on the first 3/8 of the points, leaves out the poses that can no longer beat the first
-    // stage's record (k_survivors), scores the survivors on the next 3/8, sieves again, scores what is left on the
-    // last quarter, and scans all H.  Same record, trial count and inlier set as one stage over everything.
+    // stage scores the rest on the points up to a first mark, leaves out the poses that can no longer beat the first
+    // stage's record (k_survivors), scores the survivors up to a second mark, sieves again, scores what is left on
+    // the remaining points, and scans all H.  The marks are chosen on the device from the first stage's record
+    // (k_best).  Same record, trial count and inlier set as one stage over everything.
     // score_all: the caller reads every hypothesis' counts -- one stage, nothing left out.
     const int32_t* stopped = (const int32_t*)((const double*)d_out + 12) + 5;
     const bool staged = H > 2 * RANSAC_STAGE && !score_all && w->bound && w->list && M >= 4096;
@@ -688,16 +713,20 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
         h.sample_idx = d_sample_idx; h.Rt = w->Rt; h.h0 = h0; h.stopped = later ? stopped : nullptr; h.M_dev = d_M;
         hipLaunchKernelGGL(k_hyp, dim3((h1 - h0 + 63) / 64), dim3(64), 0, ctx->stream, h);
     };
-    auto score = [&](int h0, int h1, int q0, int q1, bool later, int from_list) {   // from_list: 0 no, 1 / 2 which list
+    // the sieve marks live behind the bound and the survivor counts in the run's 256-byte block (zeroed with it)
+    int32_t* const sieve = w->bound ? (int32_t*)(w->bound + 4) : nullptr;
+    // marks: q0 / q1 index the sieve marks {0, first, second, all} instead of counting 64ths
+    auto score = [&](int h0, int h1, int q0, int q1, bool later, int from_list, bool marks) {   // from_list: 0 no, 1 / 2 which list
         ScoreArgs s;
         s.xy = d_xy; s.sxy = sxy; s.X = d_X; s.sX = sX; s.M = M; s.K = d_K; s.H = h1; s.thr2 = thr2; s.Rt = Rt;
         s.cnt = w->cnt; s.cost = w->cost; s.counters = ctx->d_counters; s.h0 = h0; s.stopped = later ? stopped : nullptr; s.M_dev = d_M;
         s.list = from_list == 0 ? nullptr : (from_list == 1 ? w->list : w->list + 4 * (size_t)H);
-        s.list_n = w->list_n + (from_list == 2 ? 1 : 0); s.q0 = q0; s.q1 = q1;
+        s.list_n = w->list_n + (from_list == 2 ? 1 : 0); s.q0 = q0; s.q1 = q1; s.qdev = marks ? sieve : nullptr;
         const int nb = (h1 - h0 + SC_HB - 1) / SC_HB;
         // survivor launches: few blocks do anything (how few is known on the device only), so each takes a short
         // piece of the range -- the launch is as long as one block
-        const int npts = (int)((long)M * (q1 - q0) / 8);
+        // points of the range: known here only without marks; with them about a third of the points
+        const int npts = marks ? M / 3 : (int)((long)M * (q1 - q0) / 64);
         const int chunks = from_list ? (npts >= 16 * 512 ? 16 : (npts >= 2048 ? 4 : 1)) : score_chunks(nb, npts);
         hipLaunchKernelGGL(k_score, dim3(nb, chunks), dim3(SC_NT), 0, ctx->stream, s);
     };
@@ -705,29 +734,30 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
         BestArgs b;
         b.cnt = w->cnt; b.cost = w->cost; b.Rt = Rt; b.H = h1; b.M = M; b.mode = o->mode; b.min_inl = o->min_inliers;
         b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 3; b.later_stage = later; b.M_dev = d_M;
-        b.bound_out = write_bound ? w->bound : nullptr;
+        b.bound_out = write_bound ? w->bound : nullptr; b.sieve_out = sieve;
+        b.qthr = (unsigned long long)(thr2 * 1048576.0);
         if (ctx->in_lane) hipLaunchKernelGGL(k_best<64>, dim3(1), dim3(64), 0, ctx->stream, b);
         else hipLaunchKernelGGL(k_best<256>, dim3(1), dim3(256), 0, ctx->stream, b);
     };
     if (!staged) {
         hyp(0, H, false);
-        score(0, H, 0, 8, false, 0);
+        score(0, H, 0, 64, false, 0, false);
         best(H, 0, false);
     } else {
         hyp(0, o->confidence > 0 ? S : H, false);
-        score(0, S, 0, 8, false, 0);
+        score(0, S, 0, 64, false, 0, false);
         best(S, 0, true);
         if (o->confidence > 0) hyp(S, H, true);
-        score(S, H, 0, 3, true, 0);                     // the first 3/8 of the points
+        score(S, H, 0, 1, true, 0, true);                     // the points up to the first mark
         SurvArgs sv;
         sv.cnt = w->cnt; sv.cost = w->cost; sv.bound = w->bound; sv.h0 = S; sv.H = H; sv.M = M; sv.mode = o->mode;
-        sv.stopped = stopped; sv.M_dev = d_M;
-        sv.seen = 3; sv.in = nullptr; sv.in_n = nullptr; sv.list = w->list; sv.list_n = w->list_n;
+        sv.stopped = stopped; sv.M_dev = d_M; sv.qdev = sieve;
+        sv.seen = 1; sv.in = nullptr; sv.in_n = nullptr; sv.list = w->list; sv.list_n = w->list_n;
         hipLaunchKernelGGL(k_survivors, dim3((4 * (H - S) + 63) / 64), dim3(64), 0, ctx->stream, sv);
-        score(S, H, 3, 6, true, 1);                     // the survivors on the next 3/8
-        sv.seen = 6; sv.in = w->list; sv.in_n = w->list_n; sv.list = w->list + 4 * (size_t)H; sv.list_n = w->list_n + 1;
+        score(S, H, 1, 2, true, 1, true);                     // the survivors up to the second mark
+        sv.seen = 2; sv.in = w->list; sv.in_n = w->list_n; sv.list = w->list + 4 * (size_t)H; sv.list_n = w->list_n + 1;
         hipLaunchKernelGGL(k_survivors, dim3((4 * (H - S) + 63) / 64), dim3(64), 0, ctx->stream, sv);
-        score(S, H, 6, 8, true, 2);                     // what is left on the last quarter
+        score(S, H, 2, 3, true, 2, true);                     // what is left on the rest
         best(H, 1, false);
     }
     InlArgs in;
@@ -1047,7 +1077,7 @@ int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_
                                            hipMemcpyDeviceToDevice, ctx->stream));
     }
     BestArgs b;
-    b.bound_out = nullptr;
+    b.bound_out = nullptr; b.sieve_out = nullptr; b.qthr = 0;
     b.cnt = w->cnt; b.cost = w->cost; b.Rt = w->Rt; b.H = H; b.M = M; b.mode = 1; b.min_inl = o->min_inliers;
     b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 8; b.later_stage = 0; b.M_dev = nullptr;
     hipLaunchKernelGGL(k_best<256>, dim3(1), dim3(256), 0, ctx->stream, b);
