@@ -739,7 +739,18 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
         if (ctx->in_lane) hipLaunchKernelGGL(k_best<64>, dim3(1), dim3(64), 0, ctx->stream, b);
         else hipLaunchKernelGGL(k_best<256>, dim3(1), dim3(256), 0, ctx->stream, b);
     };
-    if (!staged) {
+    // few points, long run, adaptive stop (the frame loop: 300 landmarks, 2000 trials, 99 %): no sieve -- there is too
+    // little to leave out -- but the prefix first all the same: the run usually ends inside it, and the launches over
+    // the other hypotheses return at once instead of generating and scoring them
+    const bool prefix = !staged && H > 2 * RANSAC_STAGE && !score_all && o->confidence > 0 && !d_poses_in;
+    if (prefix) {
+        hyp(0, S, false);
+        score(0, S, 0, 64, false, 0, false);
+        best(S, 0, false);
+        hyp(S, H, true);
+        score(S, H, 0, 64, true, 0, false);
+        best(H, 1, false);
+    } else if (!staged) {
         hyp(0, H, false);
         score(0, H, 0, 64, false, 0, false);
         best(H, 0, false);

@@ -488,15 +488,17 @@ __device__ __forceinline__ void uniform_fast(const UniArgs& a, int t, int m, int
     constexpr unsigned NONE = 0xffffffffu, IDX = 0x1ffffu, CELL_NONE = 0x7ffu;
     const float inv_nu = 1.0f / (float)a.nu, inv_nv = 1.0f / (float)a.nv;
     const int kmax = (nl + NTA - 1) / NTA;   // slots in use (uniform)
+    // two batches of independent loads (list entries, then the gathers through them): written slot by slot behind
+    // a branch each, they were sixteen dependent round trips to L2
+    int li[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) li[k] = a.klist[min(t + NTA * k, nl - 1)];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
-        const int e = t + NTA * k;
-        fp[k] = NONE; fu[k] = fv[k] = 0.0f; fk[k] = 0ull;
-        if (k < kmax && e < nl) {
-            const int i = a.klist[e];
-            fp[k] = (unsigned)i | (CELL_NONE << 17); fu[k] = a.cu[i]; fv[k] = a.cv[i];
-            fk[k] = (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull;
-        }
+        const int i = li[k];
+        fu[k] = a.cu[i]; fv[k] = a.cv[i];
+        fk[k] = (unsigned long long)__double_as_longlong(a.metric[i]) + 1ull;
+        fp[k] = (k < kmax && t + NTA * k < nl) ? ((unsigned)i | (CELL_NONE << 17)) : NONE;
     }
     UNI_T(1);
     int rounds = 0, selected = 0, remaining = nl;
