@@ -10,6 +10,8 @@ if len(sys.argv) == 3 and sys.argv[1] != "--child":
         outs.append(np.load(out))
     same = all(np.array_equal(outs[0][k], outs[1][k], equal_nan=True) for k in outs[0].files)
     print("identical bits:", same, {k: int((outs[0][k] != outs[1][k]).sum()) for k in outs[0].files})
+    if not same:
+        print("largest difference:", {k: float(np.nanmax(np.abs(outs[0][k].astype(np.float64) - outs[1][k].astype(np.float64)))) for k in outs[0].files if k[0] != "v"})
     sys.exit(0 if same else 1)
 sys.path.insert(0, ".")
 import ctypes as C

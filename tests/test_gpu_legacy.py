@@ -156,3 +156,87 @@ def test_updateW2D3D_keeps_the_msac_inliers(evolved):
     assert (g["status"], g["best_hyp"], g["best_sol"], g["trials"]) == (o["status"], o["best_hyp"], o["best_sol"], o["trials"])
     np.testing.assert_array_equal(g["inliers"], o["inliers"])
     assert g["trials"] < 10000                                                      # the 99 % stop was reached
+
+
+def sequential_v2(prev, ct, val_cand, landmarks, keypoints, curr_pose, K, recall, angle_thr, cap, max_err):
+    """modules/VisualOdometry.m:164-260 line by line: bins, one triangulation per bin and candidate against the BIN's
+    pose, the three gates, promotion without eviction, ageing.  Geometry from the oracle, one candidate at a time."""
+    landmarks = list(landmarks); keypoints = list(keypoints)
+    last_view_id = recall + 1                                                                         # :176
+    bins = {}
+    for i in np.flatnonzero(val_cand):                                                                # :188-200
+        view_id = int(prev.candidate_time_indxs[i]) + last_view_id
+        assert 1 <= view_id <= recall
+        bins.setdefault(view_id, [np.asarray(prev.candidate_first_poses[i]), []])[1].append(i)
+    ck, cfk, cfp, cti = [], [], [], []
+    n_promoted = n_full = n_z = 0
+    for view_id in range(1, recall + 1):                                                              # :208
+        if view_id not in bins:
+            continue
+        pose, idxs = bins[view_id]
+        for idx in idxs:                                                                              # :233
+            X, rep, ang, ok = oracle.triangulate(prev.candidate_first_keypoints[idx][None], ct[idx][None], pose[None], curr_pose, K)
+            if bool(ok[0]) and rep[0] < max_err and not X[0, 2] > 0:
+                n_z += 1
+            if not (bool(ok[0]) and rep[0] < max_err and X[0, 2] > 0):                                # :229-231
+                continue
+            if ang[0] > angle_thr:                                                                    # :237
+                if len(landmarks) < cap:                                                              # :238-241
+                    landmarks.append(X[0]); keypoints.append(ct[idx]); n_promoted += 1
+                else:
+                    n_full += 1
+            elif prev.candidate_time_indxs[idx] > -recall:                                            # :243
+                ck.append(ct[idx]); cfk.append(prev.candidate_first_keypoints[idx])
+                cfp.append(np.asarray(prev.candidate_first_poses[idx])); cti.append(prev.candidate_time_indxs[idx] - 1)
+    return (np.array(landmarks).reshape(-1, 3), np.array(keypoints).reshape(-1, 2), np.array(ck).reshape(-1, 2),
+            np.array(cfk).reshape(-1, 2), cfp, np.array(cti, np.int64), n_promoted, n_full, len(bins))
+
+
+@pytest.mark.parametrize("cap", [400, 0])
+def test_candidateTriangulationV2_on_the_device(evolved, cap):
+    """the multi-view variant of the class (modules/VisualOdometry.m:153-262), through k_lk and the
+    batched triangulation kernel, against the sequential restatement.  cap = 0 stands for "the landmark set is full":
+    the cap is set to the number of landmarks the frame starts with plus three, so that promotion stops early."""
+    frames, poses, prev, _ = evolved
+    vo = modules.VisualOdometry(modules.CameraParams(K1), frames[0].shape, angularThreshold=2.5, maxTemporalRecall=10,
+                                maxNumLandmarks=400, maxReprojectionError=2.0)
+    cs = modules._new_state()
+    kt, val_key, _ = vo.tracker.track(frames[5], frames[6], prev.keypoints)
+    cs.landmarks = np.asarray(prev.landmarks)[val_key]; cs.keypoints = kt[val_key]
+    n0 = len(cs.landmarks)
+    if cap == 0:
+        cap = n0 + 3
+    vo.maxNumLandmarks = cap
+    ct, val_cand, _ = vo.tracker.track(frames[5], frames[6], prev.candidate_keypoints)
+    lm, kp, ck, cfk, cfp, cti, n_promoted, n_full, n_bins = sequential_v2(prev, ct, val_cand, cs.landmarks, cs.keypoints, poses[6], K1,
+                                                                          10, 2.5, cap, 2.0)
+    out, tracked = vo.candidateTriangulationV2(frames[5], prev, frames[6], cs, poses[6])
+    np.testing.assert_array_equal(tracked, ct[val_cand])                            # :171
+    assert n_bins >= 3                                                              # candidates of several ages
+    assert len(out.landmarks) == len(lm) and len(out.candidate_keypoints) == len(ck)
+    np.testing.assert_array_equal(out.keypoints, kp)                                # same tracks, the bins' order
+    np.testing.assert_allclose(out.landmarks, lm, rtol=1e-4, atol=1e-6)
+    np.testing.assert_array_equal(out.candidate_keypoints, ck)
+    np.testing.assert_array_equal(out.candidate_first_keypoints, cfk)
+    np.testing.assert_array_equal(out.candidate_time_indxs, cti)
+    assert len(out.candidate_first_poses) == len(cfp) and all(np.array_equal(a, b) for a, b in zip(out.candidate_first_poses, cfp))
+    assert n_promoted > 0
+    if cap == n0 + 3:
+        assert n_promoted == 3 and n_full > 0 and len(lm) == cap                    # no eviction: the rest is dropped
+    else:
+        assert n_full == 0 and len(lm) == n0 + n_promoted
+
+
+def test_candidateTriangulationV2_rejects_an_index_outside_the_bins():
+    """bins{view_id, 1} with view_id < 1 is an indexing error in MATLAB (:190-193); here an IndexError."""
+    class Same:
+        def track(self, a, b, pts):
+            pts = np.asarray(pts, np.float64).reshape(-1, 2)
+            return pts.copy(), np.ones(len(pts), bool), np.ones(len(pts))
+    vo = modules.VisualOdometry(modules.CameraParams(K1), (240, 320), maxTemporalRecall=4)
+    vo.tracker = Same()
+    st = modules._new_state()
+    st.candidate_keypoints = np.array([[10.0, 10.0]]); st.candidate_first_keypoints = np.array([[11.0, 10.0]])
+    st.candidate_first_poses = [synth.pose43(np.eye(3), [0.0, 0, 0])]; st.candidate_time_indxs = np.array([-5])
+    with pytest.raises(IndexError):
+        vo.candidateTriangulationV2(None, st, None, modules._new_state(), synth.pose43(np.eye(3), [1.0, 0, 0]))

@@ -95,6 +95,34 @@ def test_free_function_policy_is_fifo(oracle_geometry):
     assert list(out.candidate_time_indxs) == [-2]            # far candidate 1 aged, far candidate 3 expired
 
 
+def test_v2_policy_bins_by_first_view_and_never_evicts(oracle_geometry):
+    """modules/VisualOdometry.m:153-262: output in the bins' order (oldest view first), promotion only while there is
+    room (:238-241), strict `<` on the reprojection error (:230), the ageing rule of :243."""
+    st, pose1, X = scripted_state()
+    vo = modules.VisualOdometry(modules.CameraParams(K), (376, 1241), angularThreshold=1.0, maxTemporalRecall=10,
+                                maxNumLandmarks=5, maxReprojectionError=2)
+    vo.tracker = FakeTracker([1, 1, 1, 1, 1, 1])
+    cs = modules._new_state(); cs.landmarks = st.landmarks; cs.keypoints = st.keypoints
+    out, tracked = vo.candidateTriangulationV2(None, st, None, cs, pose1)
+    assert len(tracked) == 6
+    # time indexes -1 -1 -3 -10 -2 -1 -> view ids 10 10 8 1 9 10: bins in view order hold candidates [3] [2] [4] [0 1 5].
+    # Near candidates 2, 4, 0, 5 pass the angle in that order; the cap of 5 leaves room for two: 2 and 4.
+    assert len(out.landmarks) == 5
+    np.testing.assert_allclose(out.landmarks[:3], st.landmarks)
+    np.testing.assert_allclose(out.landmarks[3:], X[[2, 4]], atol=1e-6)
+    np.testing.assert_allclose(out.keypoints[3:], st.candidate_keypoints[[2, 4]])
+    # far candidate 3 (age -10) expires, far candidate 1 is kept and aged; candidates 0 and 5 found no room: dropped
+    assert list(out.candidate_time_indxs) == [-2]
+    np.testing.assert_allclose(out.candidate_keypoints, st.candidate_keypoints[[1]])
+    # the strict gate: a maximum equal to a candidate's error rejects it (the first method's `<=` accepts it)
+    rep = oracle.triangulate(st.candidate_first_keypoints, st.candidate_keypoints, np.stack(st.candidate_first_poses).reshape(-1, 12), pose1, K)[1]
+    vo.maxReprojectionError = float(rep[2]); vo.maxNumLandmarks = 50
+    cs = modules._new_state(); cs.landmarks = st.landmarks; cs.keypoints = st.keypoints
+    out2, _ = vo.candidateTriangulationV2(None, st, None, cs, pose1)
+    kept = [i for i in (2, 4, 0, 5) if rep[i] < rep[2]]
+    assert 2 not in kept and len(out2.landmarks) == 3 + len(kept)
+
+
 def test_klt_tracker_option_checks():
     t = modules.KLTTracker()
     assert (t.NumPyramidLevels, t.MaxBidirectionalError, t.BlockSize, t.MaxIterations) == (4, 2.0, (41, 41), 50)

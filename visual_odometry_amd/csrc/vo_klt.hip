@@ -23,7 +23,9 @@
 
 namespace {
 
-constexpr int LK_M = 3; // LDS patch margin in pixels
+// LDS patch margin in pixels.  2: the 41 x 41 patch is 52 x 47 floats, 16 workgroups a CU (the 128-VGPR kernel's own
+// limit); 3 made it 52 x 49 and 15 a CU; 4 (fewer re-stagings, 14 a CU) was 5 % slower
+constexpr int LK_M = 2;
 
 struct LKArgs {
     const float *A, *B;
@@ -250,21 +252,22 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             // difference, VS = vertical 1-2-1 smoothing of the three rows, then the horizontal halves.
             // Gradients are kept times 8 (the 1/8 of the operator is a power of two: it is folded,
             // exactly, into G and the 2x2 inverse below).
-            float E[3][BW + 2];
             // opaque per-level copies: the mask words are re-extracted at each use (one v_bfe_i32) instead
             // of living in 30 registers across the kernel
             WinMask<W41> wm = mask;
             wm.opaque();
             // Row-major lane order (lane + 1 = the block to the right): a lane samples only the BW columns that
-            // start its block and takes the two columns that complete its Sobel support -- the first two columns
-            // of its right neighbour, the same samples by the same arithmetic -- from lane + 1 (DPP wave shift).
-            // 5 instead of 7 columns of separable lerps per row and 6 instead of 8 LDS reads.  The last block of a
-            // row of blocks has no such neighbour (lane + 1 is the first block of the next row): what it receives
-            // must only reach masked pixels, which holds when the window leaves that block at most BW - 2 columns
-            // -- the W41 window shape leaves it one (35 x 31 on the same blocks fills it: found by
+            // start its block.  What completes its Sobel support -- the vertical difference and the vertical
+            // smoothing of the first two columns of its right neighbour, and that neighbour's first centre sample --
+            // is the same arithmetic on the same samples in lane + 1 and comes from there (DPP wave shift): 5
+            // instead of 7 columns of separable lerps AND of vertical Sobel halves per row, 6 instead of 8 LDS reads.
+            // The last block of a row of blocks has no such neighbour (lane + 1 is the first block of the next row):
+            // what it receives must only reach masked pixels, which holds when the window leaves that block at most
+            // BW - 2 columns -- the W41 window shape leaves it one (35 x 31 on the same blocks fills it: found by
             // test_klt_window_classes_and_borders).  Other shapes sample all BW + 2 columns themselves.
             constexpr bool SHARE = W41 && !C::COL && BW >= 3;
             constexpr int EC = SHARE ? BW : BW + 2;   // columns of E this lane samples itself
+            float E[3][EC];
             float hp[EC];
 #pragma unroll
             for (int r = 0; r < BH + 3; ++r) {
@@ -277,10 +280,6 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                     float* er = E[(r - 1) % 3];
 #pragma unroll
                     for (int c = 0; c < EC; ++c) er[c] = hp[c] + fv * (p[c] - hp[c]);
-                    if (SHARE) {
-                        er[BW] = dpp_mov<0x130, 0xf>(er[0]);       // wave_shl:1 -- lane i reads lane i + 1
-                        er[BW + 1] = dpp_mov<0x130, 0xf>(er[1]);
-                    }
                 }
 #pragma unroll
                 for (int c = 0; c < EC; ++c) hp[c] = p[c];
@@ -289,9 +288,19 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                     const float* e0 = E[j % 3]; const float* e1 = E[(j + 1) % 3]; const float* e2 = E[(j + 2) % 3];
                     float VD[BW + 2], VS[BW + 2];
 #pragma unroll
-                    for (int c = 0; c < BW + 2; ++c) {
+                    for (int c = 0; c < EC; ++c) {
                         VD[c] = e2[c] - e0[c];
                         VS[c] = (e0[c] + 2.0f * e1[c]) + e2[c];
+                    }
+                    float ectr;   // the centre row's sample in column BW (the template intensity of pixel BW - 1)
+                    if constexpr (SHARE) {
+                        VD[BW] = dpp_mov<0x130, 0xf>(VD[0]);       // wave_shl:1 -- lane i reads lane i + 1
+                        VD[BW + 1] = dpp_mov<0x130, 0xf>(VD[1]);
+                        VS[BW] = dpp_mov<0x130, 0xf>(VS[0]);
+                        VS[BW + 1] = dpp_mov<0x130, 0xf>(VS[1]);
+                        ectr = dpp_mov<0x130, 0xf>(e1[0]);
+                    } else {
+                        ectr = e1[BW];
                     }
 #pragma unroll
                     for (int i = 0; i < BW; ++i) {
@@ -301,7 +310,8 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                         Tu[j][i] = and_bits(tu, in);
                         Tv[j][i] = and_bits(tv, in);
                         sxx += Tu[j][i] * Tu[j][i]; sxy += Tu[j][i] * Tv[j][i]; syy += Tv[j][i] * Tv[j][i];
-                        ctu += e1[i + 1] * Tu[j][i]; ctv += e1[i + 1] * Tv[j][i];
+                        const float ti = i + 1 < BW ? e1[i + 1] : ectr;
+                        ctu += ti * Tu[j][i]; ctv += ti * Tv[j][i];
                     }
                 }
             }
@@ -314,8 +324,10 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
         const float CTu = s5[3], CTv = s5[4];
         const double dif = Guu - Gvv;
         // mineig(G) / npx >= VO_MIN_EIG without the division: 2 * mineig(G) >= 2 * npx * VO_MIN_EIG
-        const double mineig2 = (Guu + Gvv) - sqrt(dif * dif + 4.0 * (Guv * Guv));
-        const double det = Guu * Gvv - Guv * Guv;
+        // explicit fma where a sum of two products could be fused either way: under -ffp-contract=fast the compiler's
+        // pick changed with unrelated edits, and with it the last bits of 5 % of the tracks (scripts/ab_bits.py)
+        const double mineig2 = (Guu + Gvv) - sqrt(fma(dif, dif, 4.0 * (Guv * Guv)));
+        const double det = fma(Guu, Gvv, -(Guv * Guv));
         float du = 0, dv = 0;
         const bool flat = !(mineig2 >= a.flat_thr);
         if (flat) {
@@ -390,10 +402,10 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                 const float Bu = (ku0 - fu * kua) - fv * (kub + fu * kuc);
                 const float Bv = (kv0 - fu * kva) - fv * (kvb + fu * kvc);
                 ++iters;
-                const float ddu = iuu * Bu + iuv * Bv;
-                const float ddv = iuv * Bu + ivv * Bv;
+                const float ddu = fmaf(iuu, Bu, iuv * Bv);
+                const float ddv = fmaf(iuv, Bu, ivv * Bv);
                 du += ddu; dv += ddv;
-                if (__builtin_amdgcn_ballot_w64(ddu * ddu + ddv * ddv < a.eps2)) break;
+                if (__builtin_amdgcn_ballot_w64(fmaf(ddu, ddu, ddv * ddv) < a.eps2)) break;
             }
             if (l == 0) { staged0 = staged; pou0 = pou; pov0 = pov; }
         }
@@ -510,7 +522,7 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
         if (fl2 & 1) ok = false;
         else {
             const double eu = p0u - bu, ev = p0v - bv;
-            const double d = sqrt(eu * eu + ev * ev);
+            const double d = sqrt(fma(eu, eu, ev * ev));
             fb = (float)d;
             if (!(d <= a.max_bidir)) ok = false;
         }

@@ -232,6 +232,52 @@ class VisualOdometry:
         curr_state.candidate_time_indxs = np.array(cti, np.int64)
         return curr_state, tracked_keypoints
 
+    def candidateTriangulationV2(self, prev_img, prev_state, curr_img, curr_state, curr_pose):
+        """modules/VisualOdometry.m:153-262 (never called by the reference).  The candidates are
+        binned by the view they were first seen in -- view id = time index + maxTemporalRecall + 1 (:176,190-200), the
+        bin's pose is the first pose filed in it (:194-196) -- and every non-empty bin, in view order, is triangulated
+        against the current view (:205-228).  Gates: valid, reprojection error STRICTLY below the maximum, world Z > 0
+        (:229-231); a candidate past the angle threshold is promoted while there is room and dropped otherwise -- no
+        eviction, no reproError bookkeeping (:238-241); the others age as in the first method (:243-252).
+        All bins go through the device in ONE batched call (each candidate carries its bin's pose); the merge runs on
+        the host in the reference's order: bins by view id, candidates by index inside a bin."""
+        landmarks = list(np.asarray(curr_state.landmarks).reshape(-1, 3))
+        keypoints = list(np.asarray(curr_state.keypoints).reshape(-1, 2))
+        ct, val_cand, _ = self.tracker.track(prev_img, curr_img, prev_state.candidate_keypoints)   # :169-171
+        tracked_keypoints = ct[val_cand]
+        last_view_id = self.maxTemporalRecall + 1                                                  # :176
+        bins = [[] for _ in range(self.maxTemporalRecall)]
+        bin_pose = [None] * self.maxTemporalRecall
+        for i in np.flatnonzero(val_cand):                                                         # :188-200
+            view_id = int(prev_state.candidate_time_indxs[i]) + last_view_id
+            if not 1 <= view_id <= self.maxTemporalRecall:     # MATLAB: index out of bounds on bins{view_id, 1}
+                raise IndexError("candidateTriangulationV2: candidate_time_indxs outside [-maxTemporalRecall, -1]")
+            if not bins[view_id - 1]:
+                bin_pose[view_id - 1] = np.asarray(prev_state.candidate_first_poses[i], np.float64)
+            bins[view_id - 1].append(int(i))
+        order = [i for b in bins for i in b]
+        ck, cfk, cfp, cti = [], [], [], []
+        if order:
+            poses0 = np.stack([bin_pose[b] for b, m in enumerate(bins) for _ in m])
+            X, rep, ang, ok = ops.triangulate_candidates(np.asarray(prev_state.candidate_first_keypoints)[order],
+                                                         np.asarray(ct)[order], poses0, curr_pose, self.cameraParams.K)
+            for j, i in enumerate(order):
+                if not (ok[j] and rep[j] < self.maxReprojectionError and X[j, 2] > 0):             # :229-231
+                    continue
+                if ang[j] > self.angularThreshold:                                                 # :237
+                    if len(landmarks) < self.maxNumLandmarks:                                      # :238-241
+                        landmarks.append(X[j]); keypoints.append(ct[i])
+                elif prev_state.candidate_time_indxs[i] > -self.maxTemporalRecall:                 # :243-252
+                    ck.append(ct[i]); cfk.append(prev_state.candidate_first_keypoints[i])
+                    cfp.append(prev_state.candidate_first_poses[i]); cti.append(prev_state.candidate_time_indxs[i] - 1)
+        curr_state.landmarks = np.array(landmarks).reshape(-1, 3)
+        curr_state.keypoints = np.array(keypoints).reshape(-1, 2)
+        curr_state.candidate_keypoints = np.array(ck).reshape(-1, 2)
+        curr_state.candidate_first_keypoints = np.array(cfk).reshape(-1, 2)
+        curr_state.candidate_first_poses = cfp
+        curr_state.candidate_time_indxs = np.array(cti, np.int64)
+        return curr_state, tracked_keypoints
+
     def processFrame(self, prev_img, curr_img, prev_state):
         """[curr_state, curr_pose, pose_status] = processFrame(obj, prev_img, curr_img, prev_state)
         (modules/VisualOdometry.m:264-346)."""
