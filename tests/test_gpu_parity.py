@@ -344,6 +344,45 @@ def test_p3p_batch_matches_golden(ctx, golden):
     np.testing.assert_allclose(m[:, 1:4], g["p3p_poses"][0, 0, 3:].reshape(3, 3), rtol=1e-8, atol=1e-8)
 
 
+def test_p3p_batch_solves_the_geometry(ctx):
+    """Evidence for the device P3P that shares no text with the oracle (the oracle's p3p.c and the kernel restate
+    the same published algorithm line by line): Kneip's construction checked in numpy.  For random poses and point
+    triples, (1) the true pose is among the four solutions, and (2) EVERY returned solution is a solution of the
+    three-point problem -- a proper rotation whose camera sees each world point along its bearing -- unless it comes
+    from a complex root (see below)."""
+    rng = np.random.default_rng(77)
+    n = 4000
+    A = rng.normal(size=(n, 3, 3))
+    Q = np.linalg.qr(A)[0]
+    Q[:, :, 0] *= np.sign(np.linalg.det(Q))[:, None]          # proper rotations, camera -> world
+    C = rng.normal(size=(n, 3)) * 3.0
+    Pc = rng.uniform(-2, 2, (n, 3, 3)) + np.array([0, 0, 6.0])   # three points in front of the camera
+    Pw = np.einsum("nij,nkj->nki", Q, Pc) + C[:, None, :]        # world = R_wc * cam + C
+    f = Pc / np.linalg.norm(Pc, axis=2, keepdims=True)
+    got = ops.p3p_batch(Pw, f)                                    # n x 4 x [C(3) R_wc(9)]
+    Cs, Rs = got[:, :, :3], got[:, :, 3:].reshape(n, 4, 3, 3)
+    err_true = np.maximum(np.abs(Cs - C[:, None]).max(2), np.abs(Rs - Q[:, None]).max((2, 3)))
+    assert (err_true.min(1) < 1e-6).mean() > 0.999 and np.median(err_true.min(1)) < 1e-10
+    # The quartic has two or four real roots; old/p3p.m:187-215 takes real() of a complex pair too, which gives the
+    # same non-solution twice.  So: at least two of the four reproduce the three bearings (proper rotations), and what
+    # does not is one of a pair of equal entries.  (Bars on the bulk: next to a double root both statements blur.)
+    cam = np.einsum("nsji,nskj->nski", Rs, Pw[:, None] - Cs[:, :, None, :])      # R_wc^T (P - C)
+    dirs = cam / np.linalg.norm(cam, axis=3, keepdims=True)
+    bear = np.abs(dirs - f[:, None]).max((2, 3))
+    solves = bear < 1e-5
+    assert ((solves.sum(1) >= 2).mean() > 0.95) and np.median(bear[solves]) < 1e-10
+    RtR = np.einsum("nsji,nsjk->nsik", Rs, Rs)
+    assert np.abs(RtR - np.eye(3)).max((2, 3))[solves].max() < 1e-6
+    assert np.abs(np.linalg.det(Rs)[solves] - 1.0).max() < 1e-6
+    twin = np.zeros((n, 4), bool)
+    for a_ in range(4):
+        for b_ in range(4):
+            if a_ != b_:
+                twin[:, a_] |= np.abs(got[:, a_] - got[:, b_]).max(1) < 1e-9
+    off = bear > 1e-3
+    assert off.any() and twin[off].mean() > 0.95
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_ransac_identical_hypotheses_bit_exact(ctx, golden, mode):
     """Inlier sets, counts and MSAC costs under IDENTICAL hypotheses (the oracle's poses)."""
