@@ -5,8 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = the hot path of one VO frame with every input resident in HBM (visual_odometry_amd/
-device.py): pyramid build, KLT track of the landmark and candidate keypoints (one launch), P3P-RANSAC pose,
-batched triangulation, candidate selection.  Default workload = BASELINE.json configs[3] (synthetic
+device.py): pyramid build, KLT track of the landmark and of the candidate keypoints, P3P-RANSAC pose,
+batched triangulation, candidate selection.  Schedule (FrameWorkload.step_ahead): the landmark track and the pose
+chain that depends on it run on the ctx's high-priority lane stream beside the candidate track on the main stream
+(modules/VisualOdometry.m:278-289 need nothing of :71), triangulation and the selection's filter half follow on the
+main stream, and the next frame's pyramid and corner detection are issued on the side stream into that tail.  Default workload = BASELINE.json configs[3] (synthetic
 1241x376, 50k keypoints per frame split into 25k landmarks + 25k candidates, 4 levels, 2k RANSAC
 hypotheses) -- the configuration the north-star target is quoted on.  N > 1: every rank runs its own
 seed-offset sequence (weak scaling, no data-path collective); RCCL gathers the statistics once.
@@ -331,7 +334,9 @@ def main():
                 valu_util = pmc.get("valu_issue_util")
                 pmc_note = ("traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch (fabric-side, Infinity-Cache hits included; "
                             "FETCH_SIZE doubled for the 16-B/lane loads) and valu_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x "
-                            "GRBM_GUI_ACTIVE / 8) from profiles/round2_k_lk_pmc.json, PMC passes of this same kernel source")
+                            "GRBM_GUI_ACTIVE / 8) from profiles/round2_k_lk_pmc.json, PMC passes of this same kernel source; by the same "
+                            "formula a kernel of nothing but v_fma_f32 reaches 0.67 at this kernel's 4 waves per SIMD and 0.75-0.82 "
+                            "at 8 (profiles/round2_valu_clock_pmc.txt)")
         except (OSError, ValueError, KeyError):
             pass
         roof = {"bound": "valu", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
@@ -364,6 +369,9 @@ def main():
                                        f"{args.keypoints} keypoints/frame ({nl} landmarks + {nc} candidates), 4-level pyramid, "
                                        f"41x41 window, <=50 iterations, fwd-bwd 2 px, {args.hyp} P3P-RANSAC hypotheses (MSAC) on the "
                                        "landmarks, batched triangulation of the candidates, min-eigen selection (keep 100)",
+                           "schedule": "landmark track -> pose chain on a high-priority stream beside the candidate track; "
+                                       "triangulation and selection filter behind both; next frame's pyramid and corner "
+                                       "detection issued ahead into that tail (VO_NO_LANE=1 / VO_NO_PREFETCH=1 switch them off)",
                            "keypoints_per_frame": args.keypoints, "hypotheses": args.hyp,
                            "parallelism": f"{world} independent sequence(s), one per GPU"},
                 "valid_fraction": stats["keypoints_valid"] / (world * args.keypoints),

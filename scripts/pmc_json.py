@@ -27,8 +27,9 @@ out = {
     "TCC_hit_rate": tot["TCC_HIT_sum"] / max(tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"], 1.0) if "TCC_HIT_sum" in tot else None,
     "per_wave": per_wave,
     "kernel_cycles_per_launch": cycles,
-    # VALU issue utilisation: a SIMD issues one wave64 VALU instruction per 2 cycles (MI355X_MICROARCH.md; measured 2.0-2.07
-    # at 4 waves per SIMD, profiles/round2_valu_clock.txt); 1024 SIMDs
+    # VALU issue utilisation against the guide's rate: one wave64 VALU instruction per 2 cycles per SIMD (MI355X_MICROARCH.md),
+    # 1024 SIMDs.  By the same formula a kernel of nothing but v_fma_f32 reaches 0.67 at 4 waves per SIMD and 0.75-0.82 at 8
+    # (profiles/round2_valu_clock_pmc.txt): that, not 1.0, is what this figure can be compared with
     "valu_issue_util": (tot.get("SQ_INSTS_VALU", 0.0) / launches) * 2.0 / (1024.0 * cycles) if cycles else None,
     "wave_time_share": {k: per_wave[k] / per_wave["SQ_WAVE_CYCLES"] for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY")
                         if k in per_wave and "SQ_WAVE_CYCLES" in per_wave},
