@@ -327,6 +327,17 @@ int vo_frame_set_image(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int 
 /* one processFrame: prev image = the last image given; returns the pose [R_WC; t_WC] and the counts */
 int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device, double pose43[12],
                      vo_frame_info* info);
+/* The same in two calls, for a loop that does not wait for a frame before it enqueues the next (no counterpart in
+ * the reference: modules/VisualOdometry.m:264-346 returns a frame's state before the next begins; here every launch
+ * of a frame is sized by the state's capacities and reads the counts on the device, so the host need not know them).
+ * vo_frame_submit enqueues one processFrame and returns; vo_frame_collect waits for the OLDEST submitted frame and
+ * returns its pose and counts.  At most VO_FRAME_MAX_PENDING frames may be submitted and not collected; results are
+ * those of vo_frame_process (which is submit + collect).  A host image is copied during the call; a device image
+ * must stay valid and unchanged until its frame has been collected.  vo_frame_set_state / _get_state / _get_counts /
+ * _set_image refuse to run while frames are pending. */
+#define VO_FRAME_MAX_PENDING 4
+int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device);
+int vo_frame_collect(vo_ctx* ctx, vo_frame_state* st, double pose43[12], vo_frame_info* info);
 /* Look-ahead (optional; no counterpart in the reference, whose loop reads, tracks and detects one after the
  * other, main.m:52-59).  Announce, before a vo_frame_process call, the image that the call AFTER it will
  * process: that image's copy, pyramid and corner detection are then issued on the ctx's side stream behind the

@@ -247,3 +247,59 @@ def test_look_ahead_changes_nothing_but_the_schedule(ctx, sequence, device_image
     p, status, info = loop.processFrame(imgs[2])
     assert np.array_equal(p, plain[1][0]) and info == plain[1][2]
     loop.close()
+
+
+@pytest.mark.parametrize("device_images", [False, True])
+@pytest.mark.parametrize("depth", [1, 2, 4])
+def test_submitted_frames_equal_processed_frames(ctx, sequence, device_images, depth):
+    """vo_frame_submit / vo_frame_collect: the host enqueues up to `depth` frames before it collects the oldest (every
+    launch sized by the capacities, the counts read on the device) -- poses, counts and states are the bits of the
+    one-call loop, with and without the look-ahead.  Pending frames block the calls that need the host's counts."""
+    frames, poses, lift = sequence
+    if device_images:
+        import torch
+        imgs = [torch.from_numpy(f).cuda() for f in frames]
+    else:
+        imgs = [np.ascontiguousarray(f) for f in frames]
+    st0 = start_state(frames[0], lift)
+    loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=160, ctx=ctx)
+    loop.set_state(st0, imgs[0])
+    plain = [loop.processFrame(imgs[k]) for k in range(1, len(imgs))]
+    plain_final = loop.get_state()
+    loop.close()
+    for announce in (False, True):
+        loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=160, ctx=ctx)
+        loop.set_state(st0, imgs[0])
+        got, pending = [], 0
+        for k in range(1, len(imgs)):
+            loop.submit(imgs[k], imgs[k + 1] if announce and k + 1 < len(imgs) else None)
+            pending += 1
+            if pending == depth:
+                got.append(loop.collect()); pending -= 1
+        if depth > 1:
+            with pytest.raises(_lib.VoError):
+                loop.get_state()                      # frames are pending: the host does not know the counts yet
+            with pytest.raises(_lib.VoError):
+                loop.processFrame(imgs[1])
+        while pending:
+            got.append(loop.collect()); pending -= 1
+        with pytest.raises(_lib.VoError):
+            loop.collect()                            # nothing left
+        assert len(got) == len(plain)
+        for (p0, s0, i0), (p1, s1, i1) in zip(plain, got):
+            assert np.array_equal(p0, p1) and s0 == s1 and i0 == i1
+        assert states_equal(loop.get_state(), plain_final)
+        loop.close()
+
+
+def test_more_than_the_allowed_frames_cannot_be_pending(ctx, sequence):
+    frames, poses, lift = sequence
+    loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=160, ctx=ctx)
+    loop.set_state(start_state(frames[0], lift), frames[0])
+    for k in range(1, 1 + FrameLoop.MAX_PENDING):
+        loop.submit(frames[k])
+    with pytest.raises(_lib.VoError):
+        loop.submit(frames[5])
+    for k in range(FrameLoop.MAX_PENDING):
+        loop.collect()
+    loop.close()

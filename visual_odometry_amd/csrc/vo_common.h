@@ -80,7 +80,8 @@ int vo_buf_reserve(vo_ctx* ctx, vo_buf* b, size_t bytes);
 int vo_launch_frame_build(vo_ctx* ctx, vo_pyr* f, const uint8_t* d_img, hipStream_t stream = nullptr);  // nullptr: ctx->stream
 int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d_pu, const double* d_pv, int n,
                   int wu, int wv, int max_iters, double eps, double max_bidir, double* d_qu, double* d_qv,
-                  uint8_t* d_valid, float* d_score, float* d_fb);
+                  uint8_t* d_valid, float* d_score, float* d_fb,
+                  const int32_t* d_n2 = nullptr);   // d_n2: the keypoint count is d_n2[0] + d_n2[1] on the device, n its upper bound
 
 struct vo_sel_work {       // device scratch of the selection pipeline
     double* resp; unsigned long long* maxbits; int32_t* blk_counts; int32_t* blk_offs;
@@ -119,7 +120,8 @@ struct vo_strides { long xi, xc; }; // element (i, c) at base[i*xi + c*xc]
 int vo_launch_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, vo_strides sxy,
                           const double* d_poses0, int pose_col_major, const int32_t* d_pose_idx, int C, int P,
                           const double* d_pose1, const double* d_K, double* d_X, vo_strides sX,
-                          double* d_reproj, double* d_angle, uint8_t* d_valid);
+                          double* d_reproj, double* d_angle, uint8_t* d_valid,
+                          const int32_t* d_C = nullptr);   // d_C: the candidate count on the device, C its upper bound
 int vo_launch_angle(vo_ctx* ctx, const double* d_X, vo_strides sX, int n, const double* d_pose0,
                     const double* d_pose1, int pose_col_major, double* d_angle);
 int vo_launch_in_front(vo_ctx* ctx, const double* d_cam, int cam_col_major, const double* d_X, vo_strides sX,

@@ -3,8 +3,10 @@
 // The MATLAB state struct lives in HBM as structure-of-arrays; the five steps of a frame run on the
 // ctx stream through the same launchers as the stand-alone entry points (vo_launch_klt, _ransac,
 // _reproj, _triangulate, _select), glued by the small ordered-compaction / merge kernels below.
-// Per frame the host reads back one small record at the end (counts + pose + status); every intermediate
-// count stays on the device and sizes its consumers from there; no point data crosses PCIe.
+// Per frame the host reads back one small record at the end (counts + pose + status); every count -- the state's
+// own sizes included -- stays on the device and its consumers are launched for the capacities and read it there, so a
+// frame can be enqueued before the one in front of it has finished (vo_frame_submit / vo_frame_collect); no point
+// data crosses PCIe.
 // Normative restatement: oracle/vo_frame.py.
 #include <string.h>
 #include <algorithm>
@@ -55,9 +57,9 @@ __global__ __launch_bounds__(1024) void k_compact(Op op, int n, int32_t* count, 
 }
 // two independent compactions in one launch: block 0 does A, block 1 does B
 template <class OpA, class OpB>
-__global__ __launch_bounds__(1024) void k_compact2(OpA a, int na, int32_t* count_a, OpB b, int nb, int32_t* count_b) {
+__global__ __launch_bounds__(1024) void k_compact2(OpA a, int na, int32_t* count_a, const int32_t* na_dev, OpB b, int nb, int32_t* count_b) {
     __shared__ int s_w[16];
-    if (blockIdx.x == 0) compact_block(a, na, count_a, nullptr, s_w);
+    if (blockIdx.x == 0) compact_block(a, na, count_a, na_dev, s_w);
     else compact_block(b, nb, count_b, nullptr, s_w);
 }
 
@@ -115,9 +117,12 @@ struct LandmarkOp {
 };
 // start of a frame, one launch: the per-frame counters and the tombstone array are cleared, and the frame's two
 // track calls (:278 landmarks, :71 candidates), which share the image pair, get their points in one array
-__global__ void k_frame_begin(int32_t* counts, uint8_t* alive, int pw, int nL, int nC, int capL, int capC, const double* kp,
+// sizes = {landmarks, candidates} of the state the frame starts from: written by the frame before (k_append_new) or
+// by vo_frame_set_state, never by the host in between
+__global__ void k_frame_begin(int32_t* counts, uint8_t* alive, int pw, const int32_t* sizes, int capL, int capC, const double* kp,
                               const double* cu, double* pin) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nL = sizes[0], nC = sizes[1];
     if (i < 16) counts[i] = 0;
     if (i < pw) alive[i] = 0;
     if (i < nL) { pin[i] = kp[i]; pin[pw + i] = kp[capL + i]; }
@@ -125,9 +130,10 @@ __global__ void k_frame_begin(int32_t* counts, uint8_t* alive, int pw, int nL, i
 }
 // after tracking, one launch: block 0 keeps the validly tracked landmarks in order (:280-281), the other blocks
 // split the candidates' results off the shared arrays
-__global__ __launch_bounds__(1024) void k_after_track(TrackedOp top, int nL, int32_t* count, int nC, int capC, int PW,
+__global__ __launch_bounds__(1024) void k_after_track(TrackedOp top, const int32_t* sizes, int32_t* count, int capC, int PW,
                                                       const double* q, const uint8_t* valid, double* cq, uint8_t* cvalid) {
     __shared__ int s_w[16];
+    const int nL = sizes[0], nC = sizes[1];
     if (blockIdx.x == 0) { compact_block(top, nL, count, nullptr, s_w); return; }
     const int c = (blockIdx.x - 1) * 1024 + threadIdx.x;
     if (c >= nC) return;
@@ -154,7 +160,8 @@ __global__ void k_identity_record(double* out, int status) {
 // taken before the edit), below the cap it is appended (:123-127).  Landmarks are never moved: an evicted
 // one is tombstoned, an accepted one appended; the ordered compaction afterwards gives the MATLAB order.
 struct MergeArgs {
-    int nC, cap, PW, capC;
+    const int32_t* nC_dev;          // the number of candidates (device)
+    int cap, PW, capC;
     const double *X, *crep, *cq;    // candidates: pitch capC
     double *wkp, *wL, *wrep; uint8_t* alive;
     const int32_t* n0;              // landmarks that survived the reprojection filter
@@ -182,12 +189,12 @@ __global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a) {
     __shared__ uint8_t s_acc[MERGE_LDS], s_surv[MERGE_LDS];
     __shared__ int s_w[16];
     const int tid = threadIdx.x;
-    const int n0 = *a.n0;
+    const int n0 = *a.n0, nC = *a.nC_dev;
     // ordered list of the promotable candidates
     int np = 0;
-    for (int i0 = 0; i0 < a.nC; i0 += 1024) {
+    for (int i0 = 0; i0 < nC; i0 += 1024) {
         const int i = i0 + tid;
-        const int f = (i < a.nC && a.c.cls(i) == 1) ? 1 : 0;
+        const int f = (i < nC && a.c.cls(i) == 1) ? 1 : 0;
         int tot;
         const int pos = block_excl_scan_1024(f, &tot, s_w);
         if (f) s_pidx[np + pos] = i;
@@ -239,11 +246,11 @@ __global__ __launch_bounds__(1024) void k_merge_list(MergeWideArgs w) {
     __shared__ int s_w[16];
     const MergeArgs& a = w.m;
     const int tid = threadIdx.x;
-    const int n0 = *a.n0;
+    const int n0 = *a.n0, nC = *a.nC_dev;
     int np = 0;
-    for (int i0 = 0; i0 < a.nC; i0 += 1024) {
+    for (int i0 = 0; i0 < nC; i0 += 1024) {
         const int i = i0 + tid;
-        const int f = (i < a.nC && a.c.cls(i) == 1) ? 1 : 0;
+        const int f = (i < nC && a.c.cls(i) == 1) ? 1 : 0;
         int tot;
         const int pos = block_excl_scan_1024(f, &tot, s_w);
         if (f) { a.plist[np + pos] = i; w.pool[n0 + np + pos] = a.crep[i]; }
@@ -321,9 +328,10 @@ __global__ void k_existing(const int32_t* counts, int capL, int capC, const doub
 // :338-345 append the new candidates: first keypoint = keypoint, first pose = this frame's, time -1
 // ... and, last kernel of a frame, gather what the host reads back into one record (one copy instead of three):
 // the pose step's record (16 doubles), the pose (12), the counters (16 int32)
-__global__ void k_append_new(int32_t* counts, int capC, const float* su, const float* sv, int pose_slot, double* cu,
+// ... and the sizes of the state the NEXT frame starts from
+__global__ void k_append_new(int32_t* counts, int capL, int capC, const float* su, const float* sv, int pose_slot, double* cu,
                              double* cf, int32_t* cpose, int32_t* ctime, const double* rsout, const double* pose_now,
-                             double* packed) {
+                             double* packed, int32_t* sizes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int nC = counts[1];
     int m = counts[2];
@@ -341,6 +349,7 @@ __global__ void k_append_new(int32_t* counts, int capC, const float* su, const f
         for (int k = 0; k < 12; ++k) packed[16 + k] = pose_now[k];
         int32_t* pc = (int32_t*)(packed + 28);
         for (int k = 0; k < 16; ++k) pc[k] = k == 3 ? nC + take : (k == 4 ? (m > room ? 1 : 0) : (k == 5 ? take : counts[k]));
+        sizes[0] = counts[0] < capL ? counts[0] : capL; sizes[1] = nC + take;
     }
 }
 
@@ -375,8 +384,13 @@ struct vo_frame_state {
     float *score, *eu, *ev, *su, *sv;
     uint8_t *valid, *flag, *cvalid, *cok, *alive, *inl;
     int32_t *pos, *plist, *counts, *slin;
+    int32_t* sizes;                         // device: {landmarks, candidates} of state s (k_append_new / set_state)
     int32_t* h_counts;                      // pinned
-    double* h_rec;                          // pinned: ransac record (16) + pose (12)
+    double* h_rec;                          // pinned: VO_FRAME_MAX_PENDING records of 40 doubles (ransac record 16, pose 12, counters)
+    // frames submitted and not collected yet, oldest first
+    hipEvent_t ev_rec[VO_FRAME_MAX_PENDING] = {};
+    int pend_frame_no[VO_FRAME_MAX_PENDING] = {};
+    int pend_head = 0, pend_count = 0;
 };
 
 #define ST_CHECK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(e__); return e__ == hipErrorOutOfMemory ? VO_ERR_OOM : VO_ERR_HIP; } } while (0)
@@ -410,6 +424,7 @@ void carve(vo_frame_state* st, char* base, size_t* total) {
     st->valid = b.take<uint8_t>(pw); st->flag = b.take<uint8_t>(cl); st->cvalid = b.take<uint8_t>(cc); st->cok = b.take<uint8_t>(cc);
     st->alive = b.take<uint8_t>(pw); st->inl = b.take<uint8_t>(cl);
     st->pos = b.take<int32_t>(pw); st->plist = b.take<int32_t>(cc); st->counts = b.take<int32_t>(16);
+    st->sizes = b.take<int32_t>(16);
     *total = b.off + 256;
 }
 int copy_image(vo_ctx* ctx, vo_frame_state* st, int slot, const uint8_t* img, int on_device, hipStream_t stream = nullptr) {
@@ -466,7 +481,8 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_counts, 16 * sizeof(int32_t), 0);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_rec, 40 * sizeof(double), 0);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_rec, VO_FRAME_MAX_PENDING * 40 * sizeof(double), 0);
+    for (int k = 0; k < VO_FRAME_MAX_PENDING && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&st->ev_rec[k], hipEventDisableTiming);
     if (e != hipSuccess) {
         ctx->last_error = std::string("frame: allocation failed: ") + hipGetErrorString(e);
         vo_frame_destroy(ctx, st);
@@ -492,6 +508,7 @@ int vo_frame_destroy(vo_ctx* ctx, vo_frame_state* st) {
     if (st->ev_ready) (void)hipEventDestroy(st->ev_ready);
     if (st->ev_fork_la) (void)hipEventDestroy(st->ev_fork_la);
     for (int k = 0; k < 2; ++k) if (st->ev_detect[k]) (void)hipEventDestroy(st->ev_detect[k]);
+    for (int k = 0; k < VO_FRAME_MAX_PENDING; ++k) if (st->ev_rec[k]) (void)hipEventDestroy(st->ev_rec[k]);
     if (st->h_counts) (void)hipHostFree(st->h_counts);
     if (st->h_rec) (void)hipHostFree(st->h_rec);
     delete st;
@@ -505,6 +522,7 @@ int vo_frame_set_state(vo_ctx* ctx, vo_frame_state* st, const double* landmarks,
     if (N > st->capL || C > st->capC) { ctx->last_error = "frame: state larger than max_landmarks / max_candidates"; return VO_ERR_BAD_ARG; }
     if ((N > 0 && (!landmarks || !keypoints || !repro)) || (C > 0 && (!ck || !cfk || !cposes || !ctime))) return VO_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
+    if (st->pend_count) { ctx->last_error = "frame: frames were submitted and not collected yet (vo_frame_collect)"; return VO_ERR_BAD_ARG; }
     { int rc = drop_lookahead(ctx, st); if (rc) return rc; }   // the frame counter decides the look-ahead's work area
     const int s = st->s, cl = st->capL, cc = st->capC;
     std::vector<double> hL(3 * (size_t)std::max(N, 1)), hk(2 * (size_t)std::max(N, 1)), hc(2 * (size_t)std::max(C, 1)), hf(2 * (size_t)std::max(C, 1));
@@ -538,12 +556,16 @@ int vo_frame_set_state(vo_ctx* ctx, vo_frame_state* st, const double* landmarks,
         ST_CHECK(hipMemcpyAsync(st->poses + 12 * (size_t)st->ring, table.data(), table.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     ST_CHECK(hipStreamSynchronize(ctx->stream));
+    const int32_t sz[2] = {N, C};
+    ST_CHECK(hipMemcpyAsync(st->sizes, sz, sizeof sz, hipMemcpyHostToDevice, ctx->stream));
+    ST_CHECK(hipStreamSynchronize(ctx->stream));
     st->nL = N; st->nC = C; st->frame_no = frame_no;
     return VO_OK;
 }
 
 int vo_frame_get_counts(vo_ctx* ctx, vo_frame_state* st, int* N, int* C) {
     if (!ctx || !st) return VO_ERR_BAD_ARG;
+    if (st->pend_count) { ctx->last_error = "frame: frames were submitted and not collected yet (vo_frame_collect)"; return VO_ERR_BAD_ARG; }
     if (N) *N = st->nL;
     if (C) *C = st->nC;
     return VO_OK;
@@ -553,6 +575,7 @@ int vo_frame_get_state(vo_ctx* ctx, vo_frame_state* st, double* landmarks, doubl
                        double* ck, double* cfk, double* cposes, int32_t* ctime) {
     if (!ctx || !st) return VO_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
+    if (st->pend_count) { ctx->last_error = "frame: frames were submitted and not collected yet (vo_frame_collect)"; return VO_ERR_BAD_ARG; }
     const int s = st->s, N = st->nL, C = st->nC, cl = st->capL, cc = st->capC;
     std::vector<double> hL(3 * (size_t)std::max(N, 1)), hk(2 * (size_t)std::max(N, 1)), hc(2 * (size_t)std::max(C, 1)), hf(2 * (size_t)std::max(C, 1)),
         table(12 * (size_t)st->P);
@@ -589,6 +612,7 @@ int vo_frame_get_state(vo_ctx* ctx, vo_frame_state* st, double* landmarks, doubl
 int vo_frame_set_image(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device) {
     if (!ctx || !st || !img) return VO_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
+    if (st->pend_count) { ctx->last_error = "frame: frames were submitted and not collected yet (vo_frame_collect)"; return VO_ERR_BAD_ARG; }
     int rc = drop_lookahead(ctx, st);
     if (rc) return rc;
     rc = upload_image(ctx, st, st->cur, img, on_device);
@@ -604,15 +628,19 @@ int vo_frame_announce(vo_ctx* ctx, vo_frame_state* st, const uint8_t* next_img, 
     return VO_OK;
 }
 
-int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device, double pose43[12], vo_frame_info* info) {
-    if (!ctx || !st || !img || !pose43 || !info) return VO_ERR_BAD_ARG;
+int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device) {
+    if (!ctx || !st || !img) return VO_ERR_BAD_ARG;
     if (!st->have_prev) { ctx->last_error = "frame: no previous image (vo_frame_set_image)"; return VO_ERR_BAD_ARG; }
+    if (st->pend_count == VO_FRAME_MAX_PENDING) { ctx->last_error = "frame: VO_FRAME_MAX_PENDING frames are waiting to be collected"; return VO_ERR_BAD_ARG; }
     (void)hipSetDevice(ctx->device);
     hipStream_t sm = ctx->stream;
     const vo_frame_opts& o = st->o;
     const int s = st->s, n = 1 - s, a = st->cur, b = (st->cur + 1) % 3, c = (st->cur + 2) % 3;
     const int cl = st->capL, cc = st->capC, pw = st->PW;
-    const int nL = st->nL, nC = st->nC;
+    // Every launch below is sized by the capacities and reads the counts on the device (st->sizes for the state the
+    // frame starts from, st->counts for what the frame finds): nothing here depends on a value the host would have
+    // to wait for.  st->nL / st->nC are the counts of the last COLLECTED frame -- a hint for the form of the merge.
+    const int nL_hint = st->nL, nC_hint = st->nC;
     const int frame_no = st->frame_no + 1;
     const int slot = frame_no % st->ring;
     double* pose_now = st->poses + 12 * (size_t)slot;
@@ -644,71 +672,65 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
         }
         if ((rc = build_pyramid(ctx, st, b))) return rc;
     }
-    hipLaunchKernelGGL(k_frame_begin, dim3(blocks(std::max(pw, 16))), dim3(256), 0, sm, st->counts, st->alive, pw, nL, nC, cl, cc,
+    hipLaunchKernelGGL(k_frame_begin, dim3(blocks(std::max(pw, 16))), dim3(256), 0, sm, st->counts, st->alive, pw, st->sizes, cl, cc,
                        st->kp[s], st->cu[s], st->pin);
 
     // [1] :278-281 and :71 track the landmarks' keypoints and the candidates in one launch; keep the
     // validly tracked landmarks in order
     // The number M of validly tracked landmarks stays on the device (counts[6]): the pose step, the
     // reprojection filter and the compaction are sized by its upper bound nL and read M themselves.
-    if (nL + nC > 0) {
-        if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->pin, st->pin + pw, nL + nC, o.klt.block_w, o.klt.block_h,
-                                o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, st->score, nullptr))) return rc;
-    }
+    if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->pin, st->pin + pw, pw, o.klt.block_w, o.klt.block_h,
+                            o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, st->score, nullptr, st->sizes))) return rc;
     // look-ahead, part 1: the point of the ctx stream behind which the side stream may start (the tracking launch
     // is the last reader of the slot and of the work area that the look-ahead overwrites)
     if (st->next_src) ST_CHECK(hipEventRecord(st->ev_fork_la, sm));
-    if (nL + nC > 0) {   // with nL == 0 block 0 writes a tracked count of 0, which the frame's clear has put there already
+    {
         TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
-        hipLaunchKernelGGL(k_after_track, dim3(1 + blocks(nC, 1024)), dim3(1024), 0, sm, top, nL, st->counts + 6, nC, cc, pw, st->q,
+        hipLaunchKernelGGL(k_after_track, dim3(1 + blocks(cc, 1024)), dim3(1024), 0, sm, top, st->sizes, st->counts + 6, cc, pw, st->q,
                            st->valid, st->cq, st->cvalid);
     }
     // [2] :285-289 pose (fewer than 4 tracked points: status 1 and the identity, as the toolbox function errors out)
-    if (nL >= 4) {
+    {   // k_best gives status 1 and the identity when fewer than 4 points were tracked
         vo_ransac_opts ro = o.pose;
         ro.seed = o.pose.seed + (uint64_t)frame_no;
         vo_ransac_work w;
         if ((rc = vo_int_ransac_work_prepare(ctx, ro.num_hyp, &w))) return rc;
         vo_strides s2 = {1, cl}, s3 = {1, cl};
-        if ((rc = vo_launch_ransac(ctx, st->vk, s2, st->vl, s3, nL, st->K, &ro, nullptr, nullptr, &w, st->rsout, st->inl, st->counts + 6, 0,
+        if ((rc = vo_launch_ransac(ctx, st->vk, s2, st->vl, s3, cl, st->K, &ro, nullptr, nullptr, &w, st->rsout, st->inl, st->counts + 6, 0,
                                    pose_now))) return rc;   // the pose step's last kernel also writes the pose (:318)
-    } else {
-        hipLaunchKernelGGL(k_identity_record, dim3(1), dim3(1), 0, sm, st->rsout, 1);
-        hipLaunchKernelGGL(k_pose_from_rt, dim3(1), dim3(1), 0, sm, st->rsout, pose_now);
     }
     // [3] :298-315 reprojection error, strict filter, survivors into the merge arrays
-    if (nL > 0) {
+    {
         vo_strides s2 = {1, cl}, s3 = {1, cl};
-        if ((rc = vo_launch_reproj(ctx, st->vk, s2, st->vl, s3, nL, pose_now, 0, st->K, st->err, st->counts + 6))) return rc;
+        if ((rc = vo_launch_reproj(ctx, st->vk, s2, st->vl, s3, cl, pose_now, 0, st->K, st->err, st->counts + 6))) return rc;
         KeptOp kop = {st->err, o.max_reproj_err, st->vk, st->vl, cl, pw, st->wkp, st->wL, st->wrep, st->alive};
-        hipLaunchKernelGGL(k_compact<KeptOp>, dim3(1), dim3(1024), 0, sm, kop, nL, st->counts + 7, st->counts + 6);
+        hipLaunchKernelGGL(k_compact<KeptOp>, dim3(1), dim3(1024), 0, sm, kop, cl, st->counts + 7, st->counts + 6);
     }
     // [4] :322 -> :63-151 triangulate the tracked candidates, classify, merge in candidate order
-    if (nC > 0) {
+    {
         vo_strides c2 = {1, cc}, c3 = {1, cc};
-        if ((rc = vo_launch_triangulate(ctx, st->cf[s], st->cq, c2, st->poses, 0, st->cpose[s], nC, st->P, pose_now, st->K, st->X, c3,
-                                        st->crep, st->cang, st->cok))) return rc;
+        if ((rc = vo_launch_triangulate(ctx, st->cf[s], st->cq, c2, st->poses, 0, st->cpose[s], cc, st->P, pose_now, st->K, st->X, c3,
+                                        st->crep, st->cang, st->cok, st->sizes + 1))) return rc;
         const ClassifyArgs ca = {st->cvalid, st->cok, st->crep, st->cang, st->ctime[s], o.max_reproj_err, o.angular_threshold_deg,
                                  o.max_temporal_recall};
         MergeArgs m;
-        m.nC = nC; m.cap = cl; m.PW = pw; m.capC = cc; m.X = st->X; m.crep = st->crep; m.cq = st->cq;
+        m.nC_dev = st->sizes + 1; m.cap = cl; m.PW = pw; m.capC = cc; m.X = st->X; m.crep = st->crep; m.cq = st->cq;
         m.wkp = st->wkp; m.wL = st->wL; m.wrep = st->wrep; m.alive = st->alive; m.n0 = st->counts + 7; m.plist = st->plist;
         m.n_promoted = st->counts + 8; m.c = ca;
-        if (pw <= MERGE_LDS && nL + nC <= MERGE_ONE_BLOCK) {   // small pools: one block does it all
+        // small pools: one block does it all.  Either form is right for any pool that fits the work arrays; which
+        // one is faster is guessed from the last collected frame's counts (the pool grows by at most `keep` a frame)
+        if (pw <= MERGE_LDS && nL_hint + nC_hint + VO_FRAME_MAX_PENDING * o.sel.keep <= MERGE_ONE_BLOCK) {
             hipLaunchKernelGGL(k_merge_par, dim3(1), dim3(1024), 0, sm, m);
         } else {                                               // the all-pairs counts spread over the chip
             MergeWideArgs mw = {m, st->pin, (uint8_t*)st->pos, (uint8_t*)st->pos + pw, st->counts + 9};
             hipLaunchKernelGGL(k_merge_list, dim3(1), dim3(1024), 0, sm, mw);
-            hipLaunchKernelGGL(k_merge_rank, dim3(blocks(16 * (nL + nC))), dim3(256), 0, sm, mw);
+            hipLaunchKernelGGL(k_merge_rank, dim3(blocks(16 * pw)), dim3(256), 0, sm, mw);
             hipLaunchKernelGGL(k_merge_write, dim3(1), dim3(1024), 0, sm, mw);
         }
         // the aged candidates and the final landmark order are independent: one launch, a block each
         CandOp cop = {ca, cc, st->cq, st->cf[s], st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]};
         LandmarkOp lop = {st->alive, pw, cl, st->wkp, st->wL, st->wrep, st->kp[n], st->L[n], st->rep[n]};
-        hipLaunchKernelGGL((k_compact2<CandOp, LandmarkOp>), dim3(2), dim3(1024), 0, sm, cop, nC, st->counts + 1, lop, pw, st->counts + 0);
-    } else {
-        LandmarkOp lop = {st->alive, pw, cl, st->wkp, st->wL, st->wrep, st->kp[n], st->L[n], st->rep[n]};
-        hipLaunchKernelGGL(k_compact<LandmarkOp>, dim3(1), dim3(1024), 0, sm, lop, pw, st->counts + 0, nullptr);
+        hipLaunchKernelGGL((k_compact2<CandOp, LandmarkOp>), dim3(2), dim3(1024), 0, sm, cop, cc, st->counts + 1, st->sizes + 1, lop, pw, st->counts + 0);
     }
     // [5b] :330-345 new candidates away from every tracked point; the number of existing points stays on the
     // device (counts[0] + counts[1]), so the host does not wait here
@@ -718,8 +740,8 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
         if ((rc = vo_launch_select_filter(ctx, sm, st->nu, st->nv, 0, st->eu, st->ev, cl + cc, st->counts, &o.sel, &selw, st->su, st->sv,
                                           st->slin, nullptr, st->counts + 2))) return rc;
     }
-    hipLaunchKernelGGL(k_append_new, dim3(blocks(std::max(o.sel.keep, 1))), dim3(256), 0, sm, st->counts, cc, st->su, st->sv, slot,
-                       st->cu[n], st->cf[n], st->cpose[n], st->ctime[n], st->rsout, pose_now, st->packed);
+    hipLaunchKernelGGL(k_append_new, dim3(blocks(std::max(o.sel.keep, 1))), dim3(256), 0, sm, st->counts, cl, cc, st->su, st->sv, slot,
+                       st->cu[n], st->cf[n], st->cpose[n], st->ctime[n], st->rsout, pose_now, st->packed, st->sizes);
     // look-ahead, part 2: the announced image's copy, pyramid and detect half on the side stream.  Enqueued here,
     // after this frame's own launches (the host's launch rate is what the loop runs at: the ctx stream must not
     // wait for launches of work it does not need), it may run since the tracking launch finished -- beside
@@ -742,19 +764,41 @@ int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on
         st->next_src = nullptr;
     }
     ST_CHECK(hipGetLastError());
-    ST_CHECK(hipMemcpyAsync(st->h_rec, st->packed, 36 * sizeof(double), hipMemcpyDeviceToHost, sm));
-    ST_CHECK(hipStreamSynchronize(sm));
-    memcpy(st->h_counts, st->h_rec + 28, 16 * sizeof(int32_t));
+    // the frame's record into the next pinned slot; whoever collects the frame waits for the slot's event only
+    const int ps = (st->pend_head + st->pend_count) % VO_FRAME_MAX_PENDING;
+    ST_CHECK(hipMemcpyAsync(st->h_rec + 40 * (size_t)ps, st->packed, 36 * sizeof(double), hipMemcpyDeviceToHost, sm));
+    ST_CHECK(hipEventRecord(st->ev_rec[ps], sm));
+    st->pend_frame_no[ps] = frame_no;
+    ++st->pend_count;
+    st->s = n; st->cur = b; st->frame_no = frame_no;
+    return VO_OK;
+}
+
+int vo_frame_collect(vo_ctx* ctx, vo_frame_state* st, double pose43[12], vo_frame_info* info) {
+    if (!ctx || !st || !pose43 || !info) return VO_ERR_BAD_ARG;
+    if (!st->pend_count) { ctx->last_error = "frame: nothing was submitted (vo_frame_submit)"; return VO_ERR_BAD_ARG; }
+    (void)hipSetDevice(ctx->device);
+    const int ps = st->pend_head;
+    ST_CHECK(hipEventSynchronize(st->ev_rec[ps]));
+    const double* rec = st->h_rec + 40 * (size_t)ps;
+    memcpy(st->h_counts, rec + 28, 16 * sizeof(int32_t));
     int32_t ri[5];
-    memcpy(ri, st->h_rec + 12, sizeof ri);
-    memcpy(pose43, st->h_rec + 16, 96);
+    memcpy(ri, rec + 12, sizeof ri);
+    memcpy(pose43, rec + 16, 96);
     info->status = ri[0]; info->trials_used = ri[3]; info->n_inliers = ri[4];
     info->n_landmarks = st->h_counts[0]; info->n_candidates = st->h_counts[3]; info->n_tracked = st->h_counts[6];
     info->n_promoted = st->h_counts[8]; info->n_new = st->h_counts[5]; info->overflow = st->h_counts[4];
-    info->frame_no = frame_no;
-    st->nL = std::min(st->h_counts[0], cl); st->nC = st->h_counts[3];
-    st->s = n; st->cur = b; st->frame_no = frame_no;
+    info->frame_no = st->pend_frame_no[ps];
+    st->nL = std::min(st->h_counts[0], st->capL); st->nC = st->h_counts[3];
+    st->pend_head = (ps + 1) % VO_FRAME_MAX_PENDING; --st->pend_count;
     return VO_OK;
+}
+
+int vo_frame_process(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_device, double pose43[12], vo_frame_info* info) {
+    if (!ctx || !st || !img || !pose43 || !info) return VO_ERR_BAD_ARG;
+    if (st->pend_count) { ctx->last_error = "frame: frames were submitted and not collected yet (vo_frame_collect)"; return VO_ERR_BAD_ARG; }
+    const int rc = vo_frame_submit(ctx, st, img, on_device);
+    return rc ? rc : vo_frame_collect(ctx, st, pose43, info);
 }
 
 } // extern "C"

@@ -124,6 +124,7 @@ struct TriArgs {
     const double* poses0; int pose_col_major; const int32_t* pose_idx; int C, P;
     const double *pose1, *K;
     double* X; vo_strides sX; double *reproj, *angle; uint8_t* valid;
+    const int32_t* C_dev;   // optional: the candidate count on the device, C its upper bound
 };
 
 __global__ __launch_bounds__(256) void k_triangulate(TriArgs a) {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void k_triangulate(TriArgs a) {
     }
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.C) return;
+    if (i >= (a.C_dev ? min(a.C, *a.C_dev) : a.C)) return;
     int pi = a.pose_idx ? a.pose_idx[i] : i;
     if (pi < 0 || pi >= a.P) { // invalid table index: flag the candidate instead of reading out of bounds
         a.valid[i] = 0; a.reproj[i] = __builtin_nan(""); a.angle[i] = __builtin_nan("");
@@ -217,12 +218,12 @@ __global__ __launch_bounds__(256) void k_reproj(const double* xy, vo_strides sxy
 int vo_launch_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, vo_strides sxy,
                           const double* d_poses0, int pose_col_major, const int32_t* d_pose_idx, int C, int P,
                           const double* d_pose1, const double* d_K, double* d_X, vo_strides sX,
-                          double* d_reproj, double* d_angle, uint8_t* d_valid) {
+                          double* d_reproj, double* d_angle, uint8_t* d_valid, const int32_t* d_C) {
     if (C <= 0) return VO_OK;
     TriArgs a;
     a.xy0 = d_xy0; a.xy1 = d_xy1; a.sxy = sxy; a.poses0 = d_poses0; a.pose_col_major = pose_col_major;
     a.pose_idx = d_pose_idx; a.C = C; a.P = P; a.pose1 = d_pose1; a.K = d_K; a.X = d_X; a.sX = sX;
-    a.reproj = d_reproj; a.angle = d_angle; a.valid = d_valid;
+    a.reproj = d_reproj; a.angle = d_angle; a.valid = d_valid; a.C_dev = d_C;
     hipLaunchKernelGGL(k_triangulate, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, a);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;

@@ -92,6 +92,28 @@ class FrameLoop:
         self.ctx.call("vo_frame_process", self.h, p, dev, ptr(pose), C.byref(info))
         return pose, info.status, {n: getattr(info, n) for n, _ in FrameInfo._fields_}
 
+    MAX_PENDING = 4      # VO_FRAME_MAX_PENDING
+
+    def submit(self, curr_img, next_img=None):
+        """Enqueue one processFrame without waiting for it (vo_frame_submit): the host runs ahead of the GPU by up to
+        MAX_PENDING frames.  A device image must stay unchanged until its frame has been collected (a reference is
+        kept here); next_img as in processFrame."""
+        keep, p, dev = self._img(curr_img)
+        if next_img is not None:
+            self._next_keep, pn, devn = self._img(next_img)
+            self.ctx.call("vo_frame_announce", self.h, pn, devn)
+        self.ctx.call("vo_frame_submit", self.h, p, dev)
+        self._pending = getattr(self, "_pending", [])
+        self._pending.append(keep)
+
+    def collect(self):
+        """-> (curr_pose, pose_status, info dict) of the OLDEST submitted frame (vo_frame_collect)."""
+        pose = np.zeros((4, 3)); info = FrameInfo()
+        self.ctx.call("vo_frame_collect", self.h, ptr(pose), C.byref(info))
+        if getattr(self, "_pending", None):
+            self._pending.pop(0)
+        return pose, info.status, {n: getattr(info, n) for n, _ in FrameInfo._fields_}
+
     def close(self):
         if self.h:
             self.ctx.call("vo_frame_destroy", self.h)
