@@ -288,7 +288,9 @@ int vo_dev_p3p_ransac_static(vo_ctx* ctx, const double* d_xy, const double* d_X,
  * {landmarks, keypoints, reproError, candidate_keypoints, candidate_first_keypoints,
  * candidate_first_poses, candidate_time_indxs} (:308-315, :338-345).  Conventions: row-major host
  * arrays, (u,v) zero-based with K in the same origin, poses 4x3 row-major [R_WC; t_WC] (:318).
- * Not thread-safe per state; everything runs on the ctx stream. ==== */
+ * Not thread-safe per state.  A frame runs on the ctx stream, on the ctx's lane stream (the landmark track and the pose
+ * chain, beside the selection of the frame before) and on its side stream (the next image's pyramid and corner
+ * detection, when announced); vo_frame_collect / vo_frame_process / vo_ctx_sync wait for all of it. ==== */
 typedef struct vo_frame_state vo_frame_state;
 typedef struct vo_frame_opts {
     int max_landmarks;            /* maxNumLandmarks, :24 */

@@ -94,19 +94,25 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
         std::vector<uint8_t> img;
         image_rows(prhs[3], &img);
         vo_mex_check(vo_frame_set_image(ctx, st, img.data(), 0), "vo_frame_set_image");
-    } else if (!strcmp(cmd, "process")) {
+    } else if (!strcmp(cmd, "process") || !strcmp(cmd, "submit") || !strcmp(cmd, "collect")) {
+        // 'process' = 'submit' + 'collect'.  A loop that calls 'submit' for frame k+1 before 'collect' for frame k keeps the
+        // GPU fed while MATLAB runs (up to VO_FRAME_MAX_PENDING frames may be out): [pose, status, counts] come from 'collect'.
         vo_frame_state* st = handle_of(prhs[1]);
         double pose[12];
         vo_frame_info info;
-        if (mxIsUint64(prhs[2])) {   // a device image of the decode pool: row-major already
-            if (nrhs > 3 && mxIsUint64(prhs[3]) && *(uint64_t*)mxGetData(prhs[3]))   // look-ahead: the frame after this one
-                vo_mex_check(vo_frame_announce(ctx, st, (const uint8_t*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[3])), 1), "vo_frame_announce");
-            vo_mex_check(vo_frame_process(ctx, st, (const uint8_t*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[2])), 1, pose, &info), "vo_frame_process");
-        } else {
-            std::vector<uint8_t> img;
-            image_rows(prhs[2], &img);
-            vo_mex_check(vo_frame_process(ctx, st, img.data(), 0, pose, &info), "vo_frame_process");
+        if (strcmp(cmd, "collect")) {
+            if (mxIsUint64(prhs[2])) {   // a device image of the decode pool: row-major already
+                if (nrhs > 3 && mxIsUint64(prhs[3]) && *(uint64_t*)mxGetData(prhs[3]))   // look-ahead: the frame after this one
+                    vo_mex_check(vo_frame_announce(ctx, st, (const uint8_t*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[3])), 1), "vo_frame_announce");
+                vo_mex_check(vo_frame_submit(ctx, st, (const uint8_t*)(uintptr_t)(*(uint64_t*)mxGetData(prhs[2])), 1), "vo_frame_submit");
+            } else {
+                std::vector<uint8_t> img;
+                image_rows(prhs[2], &img);
+                vo_mex_check(vo_frame_submit(ctx, st, img.data(), 0), "vo_frame_submit");   // the host image is copied during the call
+            }
+            if (!strcmp(cmd, "submit")) return;
         }
+        vo_mex_check(vo_frame_collect(ctx, st, pose, &info), "vo_frame_collect");
         plhs[0] = mxCreateDoubleMatrix(4, 3, mxREAL);
         for (int r = 0; r < 4; ++r)
             for (int c = 0; c < 3; ++c) mxGetPr(plhs[0])[c * 4 + r] = pose[r * 3 + c];

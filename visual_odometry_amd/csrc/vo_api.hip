@@ -136,10 +136,7 @@ int vo_ctx_sync(vo_ctx* ctx) {
 }
 
 // ---- lane: a branch of the frame's dependency graph on a second stream ----
-int vo_ctx_lane_begin(vo_ctx* ctx) {
-    if (!ctx) return VO_ERR_BAD_ARG;
-    if (ctx->in_lane) { ctx->last_error = "vo_ctx_lane_begin: a lane is already open"; return VO_ERR_BAD_ARG; }
-    (void)hipSetDevice(ctx->device);
+int vo_int_lane_ensure(vo_ctx* ctx) {
     if (!ctx->lane) {
         int lo = 0, hi = 0;   // numerically lower = higher priority
         VO_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -147,6 +144,13 @@ int vo_ctx_lane_begin(vo_ctx* ctx) {
         VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming));
         VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_done, hipEventDisableTiming));
     }
+    return VO_OK;
+}
+int vo_ctx_lane_begin(vo_ctx* ctx) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    if (ctx->in_lane) { ctx->last_error = "vo_ctx_lane_begin: a lane is already open"; return VO_ERR_BAD_ARG; }
+    (void)hipSetDevice(ctx->device);
+    { int rc = vo_int_lane_ensure(ctx); if (rc) return rc; }
     if (ctx->lane_pending) {   // an earlier branch nobody joined: the new one comes behind it anyway (same stream)
         ctx->lane_pending = false;
     }

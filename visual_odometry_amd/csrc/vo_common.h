@@ -81,7 +81,7 @@ int vo_launch_frame_build(vo_ctx* ctx, vo_pyr* f, const uint8_t* d_img, hipStrea
 int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d_pu, const double* d_pv, int n,
                   int wu, int wv, int max_iters, double eps, double max_bidir, double* d_qu, double* d_qv,
                   uint8_t* d_valid, float* d_score, float* d_fb,
-                  const int32_t* d_n2 = nullptr);   // d_n2: the keypoint count is d_n2[0] + d_n2[1] on the device, n its upper bound
+                  const int32_t* d_n = nullptr);   // d_n: the keypoint count on the device, n its upper bound
 
 struct vo_sel_work {       // device scratch of the selection pipeline
     double* resp; unsigned long long* maxbits; int32_t* blk_counts; int32_t* blk_offs;
@@ -108,6 +108,7 @@ int vo_launch_select_filter(vo_ctx* ctx, hipStream_t stream, int nu, int nv, int
 // stream waits for everything enqueued on the side stream so far
 int vo_int_side_ensure(vo_ctx* ctx);   // the side stream exists
 int vo_int_side_fork(vo_ctx* ctx);
+int vo_int_lane_ensure(vo_ctx* ctx);   // creates the ctx's lane stream (vo_ctx_lane_*) if it does not exist yet
 int vo_int_side_join(vo_ctx* ctx);
 int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is_rows, const float* d_eu,
                      const float* d_ev, int n_exist, const vo_sel_opts* o, vo_sel_work* w, float* d_out_u,

@@ -8,6 +8,7 @@
 // frame can be enqueued before the one in front of it has finished (vo_frame_submit / vo_frame_collect); no point
 // data crosses PCIe.
 // Normative restatement: oracle/vo_frame.py.
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -57,10 +58,14 @@ __global__ __launch_bounds__(1024) void k_compact(Op op, int n, int32_t* count, 
 }
 // two independent compactions in one launch: block 0 does A, block 1 does B
 template <class OpA, class OpB>
-__global__ __launch_bounds__(1024) void k_compact2(OpA a, int na, int32_t* count_a, const int32_t* na_dev, OpB b, int nb, int32_t* count_b) {
+// (count_b_clamped: the same count cut at cap_b -- the number of landmarks the next frame starts from)
+__global__ __launch_bounds__(1024) void k_compact2(OpA a, int na, int32_t* count_a, const int32_t* na_dev, OpB b, int nb, int32_t* count_b,
+                                                   int32_t* count_b_clamped, int cap_b) {
     __shared__ int s_w[16];
-    if (blockIdx.x == 0) compact_block(a, na, count_a, na_dev, s_w);
-    else compact_block(b, nb, count_b, nullptr, s_w);
+    if (blockIdx.x == 0) { compact_block(a, na, count_a, na_dev, s_w); return; }
+    compact_block(b, nb, count_b, nullptr, s_w);
+    __syncthreads();
+    if (threadIdx.x == 0) *count_b_clamped = *count_b < cap_b ? *count_b : cap_b;
 }
 
 // landmarks whose keypoint tracked validly (:280-281): (q, L) -> (vk, vl), pitch = capL
@@ -115,30 +120,13 @@ struct LandmarkOp {
         rep[d] = wrep[i];
     }
 };
-// start of a frame, one launch: the per-frame counters and the tombstone array are cleared, and the frame's two
-// track calls (:278 landmarks, :71 candidates), which share the image pair, get their points in one array
-// sizes = {landmarks, candidates} of the state the frame starts from: written by the frame before (k_append_new) or
-// by vo_frame_set_state, never by the host in between
-__global__ void k_frame_begin(int32_t* counts, uint8_t* alive, int pw, const int32_t* sizes, int capL, int capC, const double* kp,
-                              const double* cu, double* pin) {
+// start of a frame: the frame's counters and the tombstone array are cleared.  The two track calls of a frame (:278
+// landmarks, :71 candidates) read their points straight from the state arrays and are two launches -- the landmarks'
+// on the ctx's lane stream in front of the pose chain, the candidates' on the ctx stream (vo_frame_submit).
+__global__ void k_frame_begin(int32_t* counts, uint8_t* alive, int pw) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nL = sizes[0], nC = sizes[1];
     if (i < 16) counts[i] = 0;
     if (i < pw) alive[i] = 0;
-    if (i < nL) { pin[i] = kp[i]; pin[pw + i] = kp[capL + i]; }
-    else if (i < nL + nC) { const int c = i - nL; pin[i] = cu[c]; pin[pw + i] = cu[capC + c]; }
-}
-// after tracking, one launch: block 0 keeps the validly tracked landmarks in order (:280-281), the other blocks
-// split the candidates' results off the shared arrays
-__global__ __launch_bounds__(1024) void k_after_track(TrackedOp top, const int32_t* sizes, int32_t* count, int capC, int PW,
-                                                      const double* q, const uint8_t* valid, double* cq, uint8_t* cvalid) {
-    __shared__ int s_w[16];
-    const int nL = sizes[0], nC = sizes[1];
-    if (blockIdx.x == 0) { compact_block(top, nL, count, nullptr, s_w); return; }
-    const int c = (blockIdx.x - 1) * 1024 + threadIdx.x;
-    if (c >= nC) return;
-    cq[c] = q[nL + c]; cq[capC + c] = q[PW + nL + c];
-    cvalid[c] = valid[nL + c];
 }
 
 // pose [R_WC; t_WC] (:318) from the RANSAC record R_cw, t_cw: C = -R_cw^T t_cw
@@ -349,7 +337,7 @@ __global__ void k_append_new(int32_t* counts, int capL, int capC, const float* s
         for (int k = 0; k < 12; ++k) packed[16 + k] = pose_now[k];
         int32_t* pc = (int32_t*)(packed + 28);
         for (int k = 0; k < 16; ++k) pc[k] = k == 3 ? nC + take : (k == 4 ? (m > room ? 1 : 0) : (k == 5 ? take : counts[k]));
-        sizes[0] = counts[0] < capL ? counts[0] : capL; sizes[1] = nC + take;
+        sizes[1] = nC + take;   // (sizes[0], the landmarks, was written by k_compact2: the next frame's landmark branch starts there)
     }
 }
 
@@ -378,16 +366,22 @@ struct vo_frame_state {
     double *L[2], *kp[2], *rep[2], *cu[2], *cf[2];
     int32_t *cpose[2], *ctime[2];
     int s;                                  // index of the current state
-    double *poses, *K, *rsout, *packed;   // packed: what a frame's host read-back takes (k_append_new)
+    double *poses, *K, *rsout2[2], *packed;   // packed: what a frame's host read-back takes (k_append_new); rsout2: by frame parity
     // work
     double *pin, *q, *vk, *vl, *err, *cq, *X, *crep, *cang, *wkp, *wL, *wrep;
     float *score, *eu, *ev, *su, *sv;
     uint8_t *valid, *flag, *cvalid, *cok, *alive, *inl;
-    int32_t *pos, *plist, *counts, *slin;
+    int32_t *pos, *plist, *counts2[2], *slin;   // counts2: a frame's counters, by frame parity
     int32_t* sizes;                         // device: {landmarks, candidates} of state s (k_append_new / set_state)
     int32_t* h_counts;                      // pinned
     double* h_rec;                          // pinned: VO_FRAME_MAX_PENDING records of 40 doubles (ransac record 16, pose 12, counters)
     // frames submitted and not collected yet, oldest first
+    // two branches of a frame (vo_frame_submit): the landmark branch on the ctx's lane stream, the rest on the ctx stream
+    hipEvent_t ev_state = nullptr;          // ctx stream: the next state's landmarks are in place (k_compact2)
+    hipEvent_t ev_pose = nullptr;           // lane: pose, reprojection filter and its compaction are done
+    hipEvent_t ev_fork_lane = nullptr;      // lane: behind the landmarks' tracking launch (look-ahead)
+    bool state_event = false;               // ev_state stands for the current state (false after set_state / set_image)
+    bool overlap = true;                    // VO_FRAME_SERIAL=1: both branches on the ctx stream
     hipEvent_t ev_rec[VO_FRAME_MAX_PENDING] = {};
     int pend_frame_no[VO_FRAME_MAX_PENDING] = {};
     int pend_head = 0, pend_count = 0;
@@ -413,7 +407,7 @@ void carve(vo_frame_state* st, char* base, size_t* total) {
         st->cu[k] = b.take<double>(2 * cc); st->cf[k] = b.take<double>(2 * cc);
         st->cpose[k] = b.take<int32_t>(cc); st->ctime[k] = b.take<int32_t>(cc);
     }
-    st->poses = b.take<double>(12 * (size_t)st->P); st->K = b.take<double>(9); st->rsout = b.take<double>(16);
+    st->poses = b.take<double>(12 * (size_t)st->P); st->K = b.take<double>(9); st->rsout2[0] = b.take<double>(16); st->rsout2[1] = b.take<double>(16);
     st->packed = b.take<double>(40);
     st->pin = b.take<double>(2 * pw); st->q = b.take<double>(2 * pw); st->vk = b.take<double>(2 * cl); st->vl = b.take<double>(3 * cl); st->err = b.take<double>(cl);
     st->cq = b.take<double>(2 * cc); st->X = b.take<double>(3 * cc); st->crep = b.take<double>(cc); st->cang = b.take<double>(cc);
@@ -423,7 +417,7 @@ void carve(vo_frame_state* st, char* base, size_t* total) {
     st->su = b.take<float>(keep); st->sv = b.take<float>(keep); st->slin = b.take<int32_t>(keep);
     st->valid = b.take<uint8_t>(pw); st->flag = b.take<uint8_t>(cl); st->cvalid = b.take<uint8_t>(cc); st->cok = b.take<uint8_t>(cc);
     st->alive = b.take<uint8_t>(pw); st->inl = b.take<uint8_t>(cl);
-    st->pos = b.take<int32_t>(pw); st->plist = b.take<int32_t>(cc); st->counts = b.take<int32_t>(16);
+    st->pos = b.take<int32_t>(pw); st->plist = b.take<int32_t>(cc); st->counts2[0] = b.take<int32_t>(16); st->counts2[1] = b.take<int32_t>(16);
     st->sizes = b.take<int32_t>(16);
     *total = b.off + 256;
 }
@@ -478,6 +472,10 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     if (e == hipSuccess) e = hipMalloc((void**)&st->img[2], (size_t)nu * nv);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_fork_la, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_state, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_pose, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_fork_lane, hipEventDisableTiming);
+    st->overlap = !getenv("VO_FRAME_SERIAL");
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_counts, 16 * sizeof(int32_t), 0);
@@ -500,6 +498,7 @@ int vo_frame_destroy(vo_ctx* ctx, vo_frame_state* st) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);   // a look-ahead may still be running
+    if (ctx->lane) (void)hipStreamSynchronize(ctx->lane);   // ... or a landmark branch
     if (st->arena) (void)hipFree(st->arena);
     for (int k = 0; k < 3; ++k) {
         if (st->img[k]) (void)hipFree(st->img[k]);
@@ -507,6 +506,9 @@ int vo_frame_destroy(vo_ctx* ctx, vo_frame_state* st) {
     }
     if (st->ev_ready) (void)hipEventDestroy(st->ev_ready);
     if (st->ev_fork_la) (void)hipEventDestroy(st->ev_fork_la);
+    if (st->ev_state) (void)hipEventDestroy(st->ev_state);
+    if (st->ev_pose) (void)hipEventDestroy(st->ev_pose);
+    if (st->ev_fork_lane) (void)hipEventDestroy(st->ev_fork_lane);
     for (int k = 0; k < 2; ++k) if (st->ev_detect[k]) (void)hipEventDestroy(st->ev_detect[k]);
     for (int k = 0; k < VO_FRAME_MAX_PENDING; ++k) if (st->ev_rec[k]) (void)hipEventDestroy(st->ev_rec[k]);
     if (st->h_counts) (void)hipHostFree(st->h_counts);
@@ -560,6 +562,7 @@ int vo_frame_set_state(vo_ctx* ctx, vo_frame_state* st, const double* landmarks,
     ST_CHECK(hipMemcpyAsync(st->sizes, sz, sizeof sz, hipMemcpyHostToDevice, ctx->stream));
     ST_CHECK(hipStreamSynchronize(ctx->stream));
     st->nL = N; st->nC = C; st->frame_no = frame_no;
+    st->state_event = false;
     return VO_OK;
 }
 
@@ -617,7 +620,7 @@ int vo_frame_set_image(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int 
     if (rc) return rc;
     rc = upload_image(ctx, st, st->cur, img, on_device);
     if (rc) return rc;
-    st->have_prev = true;
+    st->have_prev = true; st->state_event = false;
     return VO_OK;
 }
 
@@ -638,14 +641,28 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     const int s = st->s, n = 1 - s, a = st->cur, b = (st->cur + 1) % 3, c = (st->cur + 2) % 3;
     const int cl = st->capL, cc = st->capC, pw = st->PW;
     // Every launch below is sized by the capacities and reads the counts on the device (st->sizes for the state the
-    // frame starts from, st->counts for what the frame finds): nothing here depends on a value the host would have
+    // frame starts from, `counts` for what the frame finds): nothing here depends on a value the host would have
     // to wait for.  st->nL / st->nC are the counts of the last COLLECTED frame -- a hint for the form of the merge.
     const int nL_hint = st->nL, nC_hint = st->nC;
     const int frame_no = st->frame_no + 1;
     const int slot = frame_no % st->ring;
     double* pose_now = st->poses + 12 * (size_t)slot;
+    int32_t* counts = st->counts2[frame_no & 1];      // by frame parity: the frame before may still be packing its own
+    double* rsout = st->rsout2[frame_no & 1];
     const double eps = o.klt.eps > 0 ? o.klt.eps : 0.01;
     int rc;
+    // Two branches (modules/VisualOdometry.m: the pose step :278-318 needs the landmarks only, and the landmarks of
+    // the state are final once the frame before has merged, :322 -- its selection :330-345 only adds candidates):
+    //   lane stream   landmark track -> tracked landmarks -> pose -> reprojection filter       (waits for ev_state)
+    //   ctx stream    [the frame before: selection, append]  candidate track -> (ev_pose) triangulation, merge,
+    //                 compactions -> ev_state -> selection, append, record
+    // so a frame's landmark branch runs beside the selection of the frame before it.  The loop is a chain of
+    // latency-bound launches on a nearly empty chip: what runs side by side is simply saved.
+    hipStream_t sl = sm;
+    if (st->overlap) {
+        if ((rc = vo_int_lane_ensure(ctx))) return rc;
+        sl = ctx->lane;
+    }
     // [5a] :330 the image-only half of the selection (corner response, threshold, regional maxima) runs on the
     // ctx's side stream, beside the pyramid build / tracking / pose / triangulation; its other half waits for it
     // at [5b].  If this image was announced to the previous call (vo_frame_announce), its copy, pyramid and detect
@@ -658,6 +675,7 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
                        (o.sel.keep <= 0 || ctx->sel_gen[set] == st->ahead_gen);
     if (ahead) {
         ST_CHECK(hipStreamWaitEvent(sm, st->ev_ready, 0));
+        if (sl != sm) ST_CHECK(hipStreamWaitEvent(sl, st->ev_ready, 0));
         st->ahead_src = nullptr;
     } else {
         const uint8_t* announced = st->next_src; const int announced_dev = st->next_on_device;
@@ -671,41 +689,60 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
             ST_CHECK(hipEventRecord(st->ev_detect[set], ctx->side));
         }
         if ((rc = build_pyramid(ctx, st, b))) return rc;
+        st->state_event = false;    // the pyramid was built on the ctx stream: the landmark branch starts behind it
     }
-    hipLaunchKernelGGL(k_frame_begin, dim3(blocks(std::max(pw, 16))), dim3(256), 0, sm, st->counts, st->alive, pw, st->sizes, cl, cc,
-                       st->kp[s], st->cu[s], st->pin);
+    if (!st->state_event) {         // first frame after a state / image load, or no look-ahead: behind everything so far
+        ST_CHECK(hipEventRecord(st->ev_state, sm));
+        st->state_event = true;
+    }
 
-    // [1] :278-281 and :71 track the landmarks' keypoints and the candidates in one launch; keep the
-    // validly tracked landmarks in order
-    // The number M of validly tracked landmarks stays on the device (counts[6]): the pose step, the
-    // reprojection filter and the compaction are sized by its upper bound nL and read M themselves.
-    if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->pin, st->pin + pw, pw, o.klt.block_w, o.klt.block_h,
-                            o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, st->score, nullptr, st->sizes))) return rc;
-    // look-ahead, part 1: the point of the ctx stream behind which the side stream may start (the tracking launch
-    // is the last reader of the slot and of the work area that the look-ahead overwrites)
-    if (st->next_src) ST_CHECK(hipEventRecord(st->ev_fork_la, sm));
+    // ---- landmark branch ----
+    if (sl != sm) {
+        ST_CHECK(hipStreamWaitEvent(sl, st->ev_state, 0));
+        ctx->stream = sl; ctx->in_lane = true;           // the launchers below enqueue on ctx->stream
+    }
+    auto leave_lane = [&]() { ctx->stream = sm; ctx->in_lane = false; };
+    hipLaunchKernelGGL(k_frame_begin, dim3(blocks(std::max(pw, 16))), dim3(256), 0, sl, counts, st->alive, pw);
+    // [1] :278-281 track the landmarks' keypoints (read straight from the state) and keep the validly tracked ones in
+    // order.  The number M of those stays on the device (counts[6]): the pose step, the reprojection filter and the
+    // compaction are sized by the capacity and read M themselves.
+    if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->kp[s], st->kp[s] + cl, cl, o.klt.block_w, o.klt.block_h,
+                            o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, st->score, nullptr, st->sizes + 0))) { leave_lane(); return rc; }
+    if (st->next_src && sl != sm && hipEventRecord(st->ev_fork_lane, sl) != hipSuccess) { leave_lane(); ctx->last_error = "frame: hipEventRecord failed"; return VO_ERR_HIP; }
     {
         TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
-        hipLaunchKernelGGL(k_after_track, dim3(1 + blocks(cc, 1024)), dim3(1024), 0, sm, top, st->sizes, st->counts + 6, cc, pw, st->q,
-                           st->valid, st->cq, st->cvalid);
+        hipLaunchKernelGGL(k_compact<TrackedOp>, dim3(1), dim3(1024), 0, sl, top, cl, counts + 6, st->sizes + 0);
     }
-    // [2] :285-289 pose (fewer than 4 tracked points: status 1 and the identity, as the toolbox function errors out)
-    {   // k_best gives status 1 and the identity when fewer than 4 points were tracked
+    // [2] :285-289 pose (fewer than 4 tracked points: k_best gives status 1 and the identity, as the toolbox function errors out)
+    {
         vo_ransac_opts ro = o.pose;
         ro.seed = o.pose.seed + (uint64_t)frame_no;
         vo_ransac_work w;
-        if ((rc = vo_int_ransac_work_prepare(ctx, ro.num_hyp, &w))) return rc;
+        if ((rc = vo_int_ransac_work_prepare(ctx, ro.num_hyp, &w))) { leave_lane(); return rc; }
         vo_strides s2 = {1, cl}, s3 = {1, cl};
-        if ((rc = vo_launch_ransac(ctx, st->vk, s2, st->vl, s3, cl, st->K, &ro, nullptr, nullptr, &w, st->rsout, st->inl, st->counts + 6, 0,
-                                   pose_now))) return rc;   // the pose step's last kernel also writes the pose (:318)
+        if ((rc = vo_launch_ransac(ctx, st->vk, s2, st->vl, s3, cl, st->K, &ro, nullptr, nullptr, &w, rsout, st->inl, counts + 6, 0,
+                                   pose_now))) { leave_lane(); return rc; }   // the pose step's last kernel also writes the pose (:318)
     }
     // [3] :298-315 reprojection error, strict filter, survivors into the merge arrays
     {
         vo_strides s2 = {1, cl}, s3 = {1, cl};
-        if ((rc = vo_launch_reproj(ctx, st->vk, s2, st->vl, s3, cl, pose_now, 0, st->K, st->err, st->counts + 6))) return rc;
+        if ((rc = vo_launch_reproj(ctx, st->vk, s2, st->vl, s3, cl, pose_now, 0, st->K, st->err, counts + 6))) { leave_lane(); return rc; }
         KeptOp kop = {st->err, o.max_reproj_err, st->vk, st->vl, cl, pw, st->wkp, st->wL, st->wrep, st->alive};
-        hipLaunchKernelGGL(k_compact<KeptOp>, dim3(1), dim3(1024), 0, sm, kop, cl, st->counts + 7, st->counts + 6);
+        hipLaunchKernelGGL(k_compact<KeptOp>, dim3(1), dim3(1024), 0, sl, kop, cl, counts + 7, counts + 6);
     }
+    if (sl != sm) {
+        leave_lane();
+        ST_CHECK(hipEventRecord(st->ev_pose, sl));
+    }
+
+    // ---- candidate branch and the rest, on the ctx stream ----
+    // :71 track the candidates: points from the state, results straight into the candidates' work arrays
+    if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->cu[s], st->cu[s] + cc, cc, o.klt.block_w, o.klt.block_h,
+                            o.klt.max_iters, eps, o.klt.max_bidir_err, st->cq, st->cq + cc, st->cvalid, st->score + cl, nullptr, st->sizes + 1))) return rc;
+    // look-ahead, part 1: the points of the two streams behind which the side stream may start (the tracking launches
+    // are the last readers of the slot and of the work area that the look-ahead overwrites)
+    if (st->next_src) ST_CHECK(hipEventRecord(st->ev_fork_la, sm));
+    if (sl != sm) ST_CHECK(hipStreamWaitEvent(sm, st->ev_pose, 0));
     // [4] :322 -> :63-151 triangulate the tracked candidates, classify, merge in candidate order
     {
         vo_strides c2 = {1, cc}, c3 = {1, cc};
@@ -715,33 +752,44 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
                                  o.max_temporal_recall};
         MergeArgs m;
         m.nC_dev = st->sizes + 1; m.cap = cl; m.PW = pw; m.capC = cc; m.X = st->X; m.crep = st->crep; m.cq = st->cq;
-        m.wkp = st->wkp; m.wL = st->wL; m.wrep = st->wrep; m.alive = st->alive; m.n0 = st->counts + 7; m.plist = st->plist;
-        m.n_promoted = st->counts + 8; m.c = ca;
+        m.wkp = st->wkp; m.wL = st->wL; m.wrep = st->wrep; m.alive = st->alive; m.n0 = counts + 7; m.plist = st->plist;
+        m.n_promoted = counts + 8; m.c = ca;
         // small pools: one block does it all.  Either form is right for any pool that fits the work arrays; which
         // one is faster is guessed from the last collected frame's counts (the pool grows by at most `keep` a frame)
         if (pw <= MERGE_LDS && nL_hint + nC_hint + VO_FRAME_MAX_PENDING * o.sel.keep <= MERGE_ONE_BLOCK) {
             hipLaunchKernelGGL(k_merge_par, dim3(1), dim3(1024), 0, sm, m);
         } else {                                               // the all-pairs counts spread over the chip
-            MergeWideArgs mw = {m, st->pin, (uint8_t*)st->pos, (uint8_t*)st->pos + pw, st->counts + 9};
+            MergeWideArgs mw = {m, st->pin, (uint8_t*)st->pos, (uint8_t*)st->pos + pw, counts + 9};
             hipLaunchKernelGGL(k_merge_list, dim3(1), dim3(1024), 0, sm, mw);
             hipLaunchKernelGGL(k_merge_rank, dim3(blocks(16 * pw)), dim3(256), 0, sm, mw);
             hipLaunchKernelGGL(k_merge_write, dim3(1), dim3(1024), 0, sm, mw);
         }
-        // the aged candidates and the final landmark order are independent: one launch, a block each
+        // the aged candidates and the final landmark order are independent: one launch, a block each; the landmarks'
+        // block also leaves the number of landmarks the next frame starts from (st->sizes[0])
         CandOp cop = {ca, cc, st->cq, st->cf[s], st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]};
         LandmarkOp lop = {st->alive, pw, cl, st->wkp, st->wL, st->wrep, st->kp[n], st->L[n], st->rep[n]};
-        hipLaunchKernelGGL((k_compact2<CandOp, LandmarkOp>), dim3(2), dim3(1024), 0, sm, cop, cc, st->counts + 1, st->sizes + 1, lop, pw, st->counts + 0);
+        hipLaunchKernelGGL((k_compact2<CandOp, LandmarkOp>), dim3(2), dim3(1024), 0, sm, cop, cc, counts + 1, st->sizes + 1, lop, pw, counts + 0,
+                           st->sizes + 0, cl);
     }
+    ST_CHECK(hipEventRecord(st->ev_state, sm));   // the next frame's landmark branch may start here
     // [5b] :330-345 new candidates away from every tracked point; the number of existing points stays on the
     // device (counts[0] + counts[1]), so the host does not wait here
-    hipLaunchKernelGGL(k_existing, dim3(blocks(pw)), dim3(256), 0, sm, st->counts, cl, cc, st->kp[n], st->cu[n], st->eu, st->ev);
+    hipLaunchKernelGGL(k_existing, dim3(blocks(pw)), dim3(256), 0, sm, counts, cl, cc, st->kp[n], st->cu[n], st->eu, st->ev);
     if (o.sel.keep > 0) {
         ST_CHECK(hipStreamWaitEvent(sm, st->ev_detect[set], 0));
-        if ((rc = vo_launch_select_filter(ctx, sm, st->nu, st->nv, 0, st->eu, st->ev, cl + cc, st->counts, &o.sel, &selw, st->su, st->sv,
-                                          st->slin, nullptr, st->counts + 2))) return rc;
+        if ((rc = vo_launch_select_filter(ctx, sm, st->nu, st->nv, 0, st->eu, st->ev, cl + cc, counts, &o.sel, &selw, st->su, st->sv,
+                                          st->slin, nullptr, counts + 2))) return rc;
     }
-    hipLaunchKernelGGL(k_append_new, dim3(blocks(std::max(o.sel.keep, 1))), dim3(256), 0, sm, st->counts, cl, cc, st->su, st->sv, slot,
-                       st->cu[n], st->cf[n], st->cpose[n], st->ctime[n], st->rsout, pose_now, st->packed, st->sizes);
+    hipLaunchKernelGGL(k_append_new, dim3(blocks(std::max(o.sel.keep, 1))), dim3(256), 0, sm, counts, cl, cc, st->su, st->sv, slot,
+                       st->cu[n], st->cf[n], st->cpose[n], st->ctime[n], rsout, pose_now, st->packed, st->sizes);
+    // the frame's record into the next pinned slot; whoever collects the frame waits for the slot's event only
+    // (enqueued before the look-ahead's dozen launches: the record is not held up behind host work it does not need)
+    const int ps = (st->pend_head + st->pend_count) % VO_FRAME_MAX_PENDING;
+    ST_CHECK(hipMemcpyAsync(st->h_rec + 40 * (size_t)ps, st->packed, 36 * sizeof(double), hipMemcpyDeviceToHost, sm));
+    ST_CHECK(hipEventRecord(st->ev_rec[ps], sm));
+    st->pend_frame_no[ps] = frame_no;
+    ++st->pend_count;
+    st->s = n; st->cur = b; st->frame_no = frame_no;   // the frame is in: what follows is work for the next one
     // look-ahead, part 2: the announced image's copy, pyramid and detect half on the side stream.  Enqueued here,
     // after this frame's own launches (the host's launch rate is what the loop runs at: the ctx stream must not
     // wait for launches of work it does not need), it may run since the tracking launch finished -- beside
@@ -753,6 +801,7 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         if ((rc = vo_int_frame_prepare(ctx, &st->pyr[c], st->nu, st->nv, o.klt.levels))) return rc;   // may grow (first use)
         if ((rc = vo_int_side_ensure(ctx))) return rc;
         ST_CHECK(hipStreamWaitEvent(ctx->side, st->ev_fork_la, 0));   // long satisfied by the time this is enqueued
+        if (sl != sm) ST_CHECK(hipStreamWaitEvent(ctx->side, st->ev_fork_lane, 0));
         if ((rc = copy_image(ctx, st, c, st->next_src, st->next_on_device, ctx->side))) return rc;
         if ((rc = build_pyramid(ctx, st, c, ctx->side))) return rc;
         ST_CHECK(hipEventRecord(st->ev_ready, ctx->side));
@@ -764,13 +813,6 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         st->next_src = nullptr;
     }
     ST_CHECK(hipGetLastError());
-    // the frame's record into the next pinned slot; whoever collects the frame waits for the slot's event only
-    const int ps = (st->pend_head + st->pend_count) % VO_FRAME_MAX_PENDING;
-    ST_CHECK(hipMemcpyAsync(st->h_rec + 40 * (size_t)ps, st->packed, 36 * sizeof(double), hipMemcpyDeviceToHost, sm));
-    ST_CHECK(hipEventRecord(st->ev_rec[ps], sm));
-    st->pend_frame_no[ps] = frame_no;
-    ++st->pend_count;
-    st->s = n; st->cur = b; st->frame_no = frame_no;
     return VO_OK;
 }
 

@@ -38,7 +38,7 @@ struct LKArgs {
     uint8_t* valid;
     float *score, *fb;
     unsigned long long* counters; // VO_COUNTER_SHARDS x 4
-    const int32_t* n_dev;         // optional: the launch covers an upper bound n, the number of keypoints is n_dev[0] + n_dev[1] on the device
+    const int32_t* n_dev;         // optional: the launch covers an upper bound n, the number of keypoints is *n_dev on the device
 };
 
 template <int BW_, int BH_, int LU_, int LV_, int PW_, bool COL_, int WAVES_>
@@ -486,7 +486,7 @@ template <class C, bool W41>
 __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
     __shared__ __attribute__((aligned(16))) float patch[C::PW * C::PH];
     const int lane = threadIdx.x, kp = blockIdx.x;
-    if (a.n_dev && kp >= a.n_dev[0] + a.n_dev[1]) return;   // uniform
+    if (a.n_dev && kp >= *a.n_dev) return;   // uniform
     const int lr = lane / C::NQ, lq = lane - lr * C::NQ; // this lane's (row, 16-byte piece) in a staging instruction
     // lane -> block; lanes beyond LU*LV read block 0's pixels with an all-masked window
     int lu, lv;
@@ -560,7 +560,7 @@ void launch(const LKArgs& a, hipStream_t st) {
 
 int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d_pu, const double* d_pv, int n,
                   int wu, int wv, int max_iters, double eps, double max_bidir, double* d_qu, double* d_qv,
-                  uint8_t* d_valid, float* d_score, float* d_fb, const int32_t* d_n2) {
+                  uint8_t* d_valid, float* d_score, float* d_fb, const int32_t* d_n) {
     if (n <= 0) return VO_OK;
     if (!(wu & 1) || !(wv & 1) || wu < 3 || wv < 3 || max_iters < 1) { ctx->last_error = "klt: BlockSize must be odd >= 3, MaxIterations >= 1"; return VO_ERR_BAD_ARG; }
     if (A->nu != B->nu || A->nv != B->nv || A->levels != B->levels) { ctx->last_error = "klt: frame shapes differ"; return VO_ERR_BAD_ARG; }
@@ -572,7 +572,7 @@ int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d
     a.eps2 = (float)(eps * eps); a.max_bidir = max_bidir;
     a.flat_thr = 2.0 * (double)a.npx * (double)VO_MIN_EIG;
     a.pu = d_pu; a.pv = d_pv; a.qu = d_qu; a.qv = d_qv; a.valid = d_valid; a.score = d_score; a.fb = d_fb;
-    a.counters = ctx->d_counters; a.n_dev = d_n2;
+    a.counters = ctx->d_counters; a.n_dev = d_n;
     if (wu <= CfgS::MAXU && wv <= CfgS::MAXV) launch<CfgS>(a, ctx->stream);
     else if (wu <= CfgM::MAXU && wv <= CfgM::MAXV) launch<CfgM>(a, ctx->stream);
     else if (wu <= CfgL::MAXU && wv <= CfgL::MAXV) launch<CfgL>(a, ctx->stream);
