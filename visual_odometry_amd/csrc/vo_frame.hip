@@ -123,10 +123,13 @@ struct LandmarkOp {
 // start of a frame: the frame's counters and the tombstone array are cleared.  The two track calls of a frame (:278
 // landmarks, :71 candidates) read their points straight from the state arrays and are two launches -- the landmarks'
 // on the ctx's lane stream in front of the pose chain, the candidates' on the ctx stream (vo_frame_submit).
-__global__ void k_frame_begin(int32_t* counts, uint8_t* alive, int pw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 16) counts[i] = 0;
-    if (i < pw) alive[i] = 0;
+// ... in the launch that keeps the validly tracked landmarks in order (:280-281): one block, clear first
+__global__ __launch_bounds__(1024) void k_tracked(int32_t* counts, uint8_t* alive, int pw, TrackedOp top, int capL, const int32_t* nL_dev) {
+    __shared__ int s_w[16];
+    if (threadIdx.x < 16) counts[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < pw; i += 1024) alive[i] = 0;
+    __syncthreads();                                     // counts[6] is cleared before the compaction writes it
+    compact_block(top, capL, counts + 6, nL_dev, s_w);
 }
 
 // pose [R_WC; t_WC] (:318) from the RANSAC record R_cw, t_cw: C = -R_cw^T t_cw
@@ -702,16 +705,15 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         ctx->stream = sl; ctx->in_lane = true;           // the launchers below enqueue on ctx->stream
     }
     auto leave_lane = [&]() { ctx->stream = sm; ctx->in_lane = false; };
-    hipLaunchKernelGGL(k_frame_begin, dim3(blocks(std::max(pw, 16))), dim3(256), 0, sl, counts, st->alive, pw);
     // [1] :278-281 track the landmarks' keypoints (read straight from the state) and keep the validly tracked ones in
     // order.  The number M of those stays on the device (counts[6]): the pose step, the reprojection filter and the
     // compaction are sized by the capacity and read M themselves.
     if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->kp[s], st->kp[s] + cl, cl, o.klt.block_w, o.klt.block_h,
                             o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, st->score, nullptr, st->sizes + 0))) { leave_lane(); return rc; }
     if (st->next_src && sl != sm && hipEventRecord(st->ev_fork_lane, sl) != hipSuccess) { leave_lane(); ctx->last_error = "frame: hipEventRecord failed"; return VO_ERR_HIP; }
-    {
+    {   // (the frame's counters and tombstones are cleared by the same launch)
         TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
-        hipLaunchKernelGGL(k_compact<TrackedOp>, dim3(1), dim3(1024), 0, sl, top, cl, counts + 6, st->sizes + 0);
+        hipLaunchKernelGGL(k_tracked, dim3(1), dim3(1024), 0, sl, counts, st->alive, pw, top, cl, st->sizes + 0);
     }
     // [2] :285-289 pose (fewer than 4 tracked points: k_best gives status 1 and the identity, as the toolbox function errors out)
     {
@@ -774,11 +776,11 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     ST_CHECK(hipEventRecord(st->ev_state, sm));   // the next frame's landmark branch may start here
     // [5b] :330-345 new candidates away from every tracked point; the number of existing points stays on the
     // device (counts[0] + counts[1]), so the host does not wait here
-    hipLaunchKernelGGL(k_existing, dim3(blocks(pw)), dim3(256), 0, sm, counts, cl, cc, st->kp[n], st->cu[n], st->eu, st->ev);
+    // (the single cast of [keypoints; candidate_keypoints], :330-331, happens inside the filter's kernel)
     if (o.sel.keep > 0) {
         ST_CHECK(hipStreamWaitEvent(sm, st->ev_detect[set], 0));
-        if ((rc = vo_launch_select_filter(ctx, sm, st->nu, st->nv, 0, st->eu, st->ev, cl + cc, counts, &o.sel, &selw, st->su, st->sv,
-                                          st->slin, nullptr, counts + 2))) return rc;
+        if ((rc = vo_launch_select_filter(ctx, sm, st->nu, st->nv, 0, nullptr, nullptr, cl + cc, counts, &o.sel, &selw, st->su, st->sv,
+                                          st->slin, nullptr, counts + 2, st->kp[n], cl, st->cu[n], cc))) return rc;
     }
     hipLaunchKernelGGL(k_append_new, dim3(blocks(std::max(o.sel.keep, 1))), dim3(256), 0, sm, counts, cl, cc, st->su, st->sv, slot,
                        st->cu[n], st->cf[n], st->cpose[n], st->ctime[n], rsout, pose_now, st->packed, st->sizes);

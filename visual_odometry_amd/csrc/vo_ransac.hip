@@ -254,6 +254,9 @@ struct HypArgs {
     int h0;                 // first hypothesis of this launch (a later stage of the adaptive run)
     const int32_t* stopped; // non-null: the earlier stage's "adaptive stop reached" flag; nothing to do when set
     const int32_t* M_dev;   // non-null: the point count lives on the device, M is only its upper bound
+    // non-null: the run's sums start at zero HERE instead of in a launch of their own (k_zero): every hypothesis clears
+    // its four counts and costs, hypothesis 0 the run's 256-byte block (bound, survivor counts, sieve marks)
+    int32_t* zcnt; unsigned long long* zcost; unsigned long long* zblock;
 };
 
 // The pose chain may run on the ctx's lane stream beside a tracking launch that fills every SIMD (vo_ctx_lane_*):
@@ -265,6 +268,13 @@ __global__ __launch_bounds__(64, 4) void k_hyp(HypArgs a) {   // <= 128 VGPRs: f
     VO_POSE_PRIO();
     const int h = a.h0 + blockIdx.x * 64 + threadIdx.x;
     if (h >= a.H || (a.stopped && *a.stopped)) return;
+    if (a.zcnt) {
+        *reinterpret_cast<int4*>(a.zcnt + 4 * (long)h) = make_int4(0, 0, 0, 0);
+        *reinterpret_cast<ulonglong2*>(a.zcost + 4 * (long)h) = make_ulonglong2(0ull, 0ull);
+        *reinterpret_cast<ulonglong2*>(a.zcost + 4 * (long)h + 2) = make_ulonglong2(0ull, 0ull);
+        if (h == 0)
+            for (int k = 0; k < 32; ++k) a.zblock[k] = 0ull;
+    }
     if (a.M_dev) { a.M = min(a.M, *a.M_dev); if (a.M < 4) return; }
     double K[9];
     for (int k = 0; k < 9; ++k) K[k] = a.K[k];
@@ -702,7 +712,10 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
     // without a confidence nothing can end the run early: a short first stage is enough to set the bound, and all
     // hypotheses are generated in one launch
     const int S = o->confidence > 0 ? RANSAC_STAGE : RANSAC_STAGE / 4;
-    {   // counts, costs, bound, list lengths start at zero
+    // counts, costs, bound, list lengths start at zero: cleared by the hypothesis generator (every hypothesis its own
+    // sums), or, when the caller supplies the poses and no generator runs, by a launch of its own
+    const bool zero_in_hyp = !d_poses_in && w->bound;
+    if (!zero_in_hyp) {
         const long nwords = (long)(w->zero_bytes / 4);
         hipLaunchKernelGGL(k_zero, dim3((unsigned)((nwords + 63) / 64)), dim3(64), 0, ctx->stream, (unsigned*)w->cnt, nwords);
     }
@@ -711,6 +724,7 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
         HypArgs h;
         h.xy = d_xy; h.sxy = sxy; h.X = d_X; h.sX = sX; h.M = M; h.K = d_K; h.H = h1; h.seed = o->seed;
         h.sample_idx = d_sample_idx; h.Rt = w->Rt; h.h0 = h0; h.stopped = later ? stopped : nullptr; h.M_dev = d_M;
+        h.zcnt = zero_in_hyp ? w->cnt : nullptr; h.zcost = w->cost; h.zblock = w->bound;
         hipLaunchKernelGGL(k_hyp, dim3((h1 - h0 + 63) / 64), dim3(64), 0, ctx->stream, h);
     };
     // the sieve marks live behind the bound and the survivor counts in the run's 256-byte block (zeroed with it)

@@ -396,11 +396,19 @@ __global__ __launch_bounds__(256) void k_grid_fill(const float* __restrict__ cu,
 // so the chain is kept short: the span's two ends and the count are loaded together, the span is walked four
 // corners at a time.  One-wave blocks: the launch sits on the frame's critical path right behind a tracking launch
 // that may still hold most of the chip.
-__global__ __launch_bounds__(64) void k_kill(const float* __restrict__ eu, const float* __restrict__ ev, int ne,
-                                              const int32_t* __restrict__ ne_dev, GridArgs g, float thr_d2, uint8_t* keep) {
+// The existing points: two float arrays, or -- the frame loop's state, modules/VisualOdometry.m:330-331
+// `single([keypoints; candidate_keypoints])` -- two structure-of-arrays double arrays cast here (ne_dev[0] landmarks of
+// pitch capL, then ne_dev[1] candidates of pitch capC) instead of by a launch of their own.
+struct ExistSrc { const float *eu, *ev; const double *kpL, *cuC; int capL, capC; };
+__global__ __launch_bounds__(64) void k_kill(ExistSrc src, int ne, const int32_t* __restrict__ ne_dev, GridArgs g, float thr_d2, uint8_t* keep) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= (ne_dev ? ne_dev[0] + ne_dev[1] : ne)) return;
-    const float pu = eu[i], pv = ev[i];
+    float pu, pv;
+    if (src.kpL) {
+        const int nL = ne_dev[0];
+        if (i < nL) { pu = (float)src.kpL[i]; pv = (float)src.kpL[src.capL + i]; }
+        else { const int c = i - nL; pu = (float)src.cuC[c]; pv = (float)src.cuC[src.capC + c]; }
+    } else { pu = src.eu[i]; pv = src.ev[i]; }
     const int c0u = grid_cell1(pu, g.inv_cs, g.gu), c0v = grid_cell1(pv, g.inv_cs, g.gv);
     const int cv_ = c0v + (int)blockIdx.y - 1;
     if (cv_ < 0 || cv_ >= g.gv) return;
@@ -903,11 +911,14 @@ int vo_launch_select_detect(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_im
 int vo_launch_select_filter(vo_ctx* ctx, hipStream_t stream, int nu, int nv, int u_is_rows, const float* d_eu,
                             const float* d_ev, int n_exist, const int32_t* ne_dev, const vo_sel_opts* o, vo_sel_work* w,
                             float* d_out_u, float* d_out_v, int32_t* d_out_lin, double* d_out_metric,
-                            int32_t* d_out_count) {
+                            int32_t* d_out_count, const double* d_kpL, int capL, const double* d_cuC, int capC) {
     if (o->keep < 0 || n_exist < 0) { ctx->last_error = "select: negative count"; return VO_ERR_BAD_ARG; }
+    if (d_kpL && (!ne_dev || !d_cuC)) { ctx->last_error = "select: the state form of the existing points needs device counts"; return VO_ERR_BAD_ARG; }
     const float thr_d2 = d2_threshold((float)o->min_distance);
-    if (n_exist > 0 && thr_d2 > 0.0f)   // otherwise every corner keeps the flag the detect half gave it
-        hipLaunchKernelGGL(k_kill, dim3((n_exist + 63) / 64, 3), dim3(64), 0, stream, d_eu, d_ev, n_exist, ne_dev, grid_args(w), thr_d2, w->keep);
+    if (n_exist > 0 && thr_d2 > 0.0f) {  // otherwise every corner keeps the flag the detect half gave it
+        const ExistSrc src = {d_eu, d_ev, d_kpL, d_cuC, capL, capC};
+        hipLaunchKernelGGL(k_kill, dim3((n_exist + 63) / 64, 3), dim3(64), 0, stream, src, n_exist, ne_dev, grid_args(w), thr_d2, w->keep);
+    }
     UniArgs a;
     a.cu = w->lu; a.cv = w->lv; a.metric = w->metric; a.lin = w->lin; a.keep = w->keep; a.sel = w->sel; a.m0 = w->m0;
     a.n_keep = o->keep; a.nu = nu; a.nv = nv; a.u_is_rows = u_is_rows;
@@ -924,7 +935,7 @@ int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is
     int rc = vo_launch_select_detect(ctx, ctx->stream, d_img, nu, nv, o, w);
     if (rc) return rc;
     return vo_launch_select_filter(ctx, ctx->stream, nu, nv, u_is_rows, d_eu, d_ev, n_exist, nullptr, o, w, d_out_u, d_out_v,
-                                   d_out_lin, d_out_metric, d_out_count);
+                                   d_out_lin, d_out_metric, d_out_count, nullptr, 0, nullptr, 0);
 }
 
 int vo_greedy_num_blocks(long n) { return (int)((n + (long)GR_BLOCK * GR_PER - 1) / ((long)GR_BLOCK * GR_PER)); }
