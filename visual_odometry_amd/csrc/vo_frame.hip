@@ -132,20 +132,6 @@ __global__ __launch_bounds__(1024) void k_tracked(int32_t* counts, uint8_t* aliv
     compact_block(top, capL, counts + 6, nL_dev, s_w);
 }
 
-// pose [R_WC; t_WC] (:318) from the RANSAC record R_cw, t_cw: C = -R_cw^T t_cw
-__global__ void k_pose_from_rt(const double* out, double* pose) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int k = 0; k < 9; ++k) pose[k] = out[k];
-    for (int c = 0; c < 3; ++c) pose[9 + c] = -((out[c] * out[9] + out[3 + c] * out[10]) + out[6 + c] * out[11]);
-}
-__global__ void k_identity_record(double* out, int status) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (int k = 0; k < 9; ++k) out[k] = (k % 4 == 0) ? 1.0 : 0.0;
-    out[9] = out[10] = out[11] = 0.0;
-    int32_t* info = (int32_t*)(out + 12);
-    info[0] = status; info[1] = -1; info[2] = -1; info[3] = 0; info[4] = 0;
-}
-
 // The order-dependent merge of :87-142 over the promotable candidates, in candidate order: at the landmark
 // cap a candidate replaces the FIRST maximum of reproError if its own error is not larger (:116-122, maximum
 // taken before the edit), below the cap it is appended (:123-127).  Landmarks are never moved: an evicted
@@ -304,18 +290,6 @@ __global__ __launch_bounds__(1024) void k_merge_write(MergeWideArgs w) {
     if (tid == 0) *a.n_promoted = prom;
 }
 
-// :330-331 [keypoints; candidate_keypoints] cast to single
-__global__ void k_existing(const int32_t* counts, int capL, int capC, const double* kp, const double* cu, float* eu, float* ev) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nL = counts[0], nC = counts[1];
-    if (t < capL) {
-        if (t < nL) { eu[t] = (float)kp[t]; ev[t] = (float)kp[capL + t]; }
-    } else {
-        const int c = t - capL;
-        if (c < nC) { eu[nL + c] = (float)cu[c]; ev[nL + c] = (float)cu[capC + c]; }
-    }
-}
-
 // :338-345 append the new candidates: first keypoint = keypoint, first pose = this frame's, time -1
 // ... and, last kernel of a frame, gather what the host reads back into one record (one copy instead of three):
 // the pose step's record (16 doubles), the pose (12), the counters (16 int32)
@@ -372,8 +346,8 @@ struct vo_frame_state {
     double *poses, *K, *rsout2[2], *packed;   // packed: what a frame's host read-back takes (k_append_new); rsout2: by frame parity
     // work
     double *pin, *q, *vk, *vl, *err, *cq, *X, *crep, *cang, *wkp, *wL, *wrep;
-    float *score, *eu, *ev, *su, *sv;
-    uint8_t *valid, *flag, *cvalid, *cok, *alive, *inl;
+    float *score, *su, *sv;
+    uint8_t *valid, *cvalid, *cok, *alive, *inl;
     int32_t *pos, *plist, *counts2[2], *slin;   // counts2: a frame's counters, by frame parity
     int32_t* sizes;                         // device: {landmarks, candidates} of state s (k_append_new / set_state)
     int32_t* h_counts;                      // pinned
@@ -412,13 +386,13 @@ void carve(vo_frame_state* st, char* base, size_t* total) {
     }
     st->poses = b.take<double>(12 * (size_t)st->P); st->K = b.take<double>(9); st->rsout2[0] = b.take<double>(16); st->rsout2[1] = b.take<double>(16);
     st->packed = b.take<double>(40);
-    st->pin = b.take<double>(2 * pw); st->q = b.take<double>(2 * pw); st->vk = b.take<double>(2 * cl); st->vl = b.take<double>(3 * cl); st->err = b.take<double>(cl);
+    st->pin = b.take<double>(2 * pw);   /* scratch of the wide merge */ st->q = b.take<double>(2 * pw); st->vk = b.take<double>(2 * cl); st->vl = b.take<double>(3 * cl); st->err = b.take<double>(cl);
     st->cq = b.take<double>(2 * cc); st->X = b.take<double>(3 * cc); st->crep = b.take<double>(cc); st->cang = b.take<double>(cc);
     st->wkp = b.take<double>(2 * pw); st->wL = b.take<double>(3 * pw); st->wrep = b.take<double>(pw);
-    st->score = b.take<float>(pw); st->eu = b.take<float>(pw); st->ev = b.take<float>(pw);
+    st->score = b.take<float>(pw);
     const size_t keep = (size_t)std::max(st->o.sel.keep, 1);
     st->su = b.take<float>(keep); st->sv = b.take<float>(keep); st->slin = b.take<int32_t>(keep);
-    st->valid = b.take<uint8_t>(pw); st->flag = b.take<uint8_t>(cl); st->cvalid = b.take<uint8_t>(cc); st->cok = b.take<uint8_t>(cc);
+    st->valid = b.take<uint8_t>(pw); st->cvalid = b.take<uint8_t>(cc); st->cok = b.take<uint8_t>(cc);
     st->alive = b.take<uint8_t>(pw); st->inl = b.take<uint8_t>(cl);
     st->pos = b.take<int32_t>(pw); st->plist = b.take<int32_t>(cc); st->counts2[0] = b.take<int32_t>(16); st->counts2[1] = b.take<int32_t>(16);
     st->sizes = b.take<int32_t>(16);
