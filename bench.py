@@ -277,6 +277,11 @@ def main():
     # VO_REHEARSE_ONE_GPU=1: every rank on device 0 with gloo for the statistics -- a rehearsal of the
     # N > 1 code path on a one-GPU box (the numbers mean nothing); never set by the driver
     rehearse = bool(os.environ.get("VO_REHEARSE_ONE_GPU"))
+    if rehearse:
+        # several processes on ONE GPU: the ctx's high-priority lane stream of one process starves the other's streams
+        # for good (a hang, found by this rehearsal); at the ctx stream's priority they get along.  One process per GPU
+        # -- what --gpus N runs everywhere else -- is not affected.
+        os.environ.setdefault("VO_LANE_NORMAL_PRIORITY", "1")
     rank, local_rank, world = dist.init("gloo" if rehearse else None)
     if rehearse:
         local_rank = 0

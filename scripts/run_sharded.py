@@ -28,6 +28,8 @@ if "--gpus" in sys.argv:                            # start the ranks from here,
 rehearse = bool(os.environ.get("VO_REHEARSE_ONE_GPU"))
 if not rehearse:
     os.environ["VO_USE_LOCAL_RANK"] = "1"          # Context.default() = this rank's GPU
+else:
+    os.environ.setdefault("VO_LANE_NORMAL_PRIORITY", "1")   # several processes on one GPU: see bench.py
 
 import numpy as np
 

@@ -1,5 +1,6 @@
 // vo_api.hip -- the C ABI of libvo_hip.so (include/vo_hip.h): context, host-pointer entry points
 // (marshal -> device -> launch -> copy back) and device-pointer entry points.
+#include <stdlib.h>
 #include "vo_common.h"
 #include <algorithm>
 #include <cmath>
@@ -140,7 +141,9 @@ int vo_int_lane_ensure(vo_ctx* ctx) {
     if (!ctx->lane) {
         int lo = 0, hi = 0;   // numerically lower = higher priority
         VO_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        VO_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->lane, hipStreamNonBlocking, hi));
+        // VO_LANE_NORMAL_PRIORITY=1: the lane at the ctx stream's priority (A/B switch; see DESIGN "Schedule of a step")
+        if (getenv("VO_LANE_NORMAL_PRIORITY")) VO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->lane, hipStreamNonBlocking));
+        else VO_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->lane, hipStreamNonBlocking, hi));
         VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming));
         VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_done, hipEventDisableTiming));
     }
