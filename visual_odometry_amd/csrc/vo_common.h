@@ -104,7 +104,8 @@ int vo_launch_select_filter(vo_ctx* ctx, hipStream_t stream, int nu, int nv, int
                             const float* d_ev, int n_exist, const int32_t* ne_dev, const vo_sel_opts* o, vo_sel_work* w,
                             float* d_out_u, float* d_out_v, int32_t* d_out_lin, double* d_out_metric,
                             int32_t* d_out_count,
-                            const double* d_kpL = nullptr, int capL = 0, const double* d_cuC = nullptr, int capC = 0);
+                            const double* d_kpL = nullptr, int capL = 0, const double* d_cuC = nullptr, int capC = 0,
+                            hipEvent_t after_kill = nullptr);   // recorded between the two launches (vo_frame_submit)
 // side stream: fork = the side stream waits for everything enqueued on the ctx stream so far; join = the ctx
 // stream waits for everything enqueued on the side stream so far
 int vo_int_side_ensure(vo_ctx* ctx);   // the side stream exists

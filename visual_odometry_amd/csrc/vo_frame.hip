@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <vector>
 #include "vo_common.h"
+#include "vo_dev_math.h"
 
 namespace {
 
@@ -88,6 +89,67 @@ struct KeptOp {
         alive[d] = 1;
     }
 };
+// The end of the pose step and what follows it on the tracked landmarks, in one block (three launches before: the
+// pose step's k_inliers, k_reproj, the ordered compaction): the pose [R_WC; t_WC] of the record (:318), the inlier
+// flags and their number (the arithmetic of k_inliers, vo_ransac.hip), the reprojection error of EVERY tracked
+// landmark (:298-300, the arithmetic of k_reproj, vo_geom.hip), the strict filter (:302) and the survivors in order
+// into the merge arrays (:308-315).  The device functions are the same source in all three files (vo_dev_math.h).
+struct PoseTailArgs {
+    const double *vk, *vl; int capL; const int32_t* M_dev; const double* K; double thr2;
+    double* rsout; uint8_t* inl; double* pose_now; double* err; KeptOp kop; int32_t* count;
+};
+__global__ __launch_bounds__(1024) void k_pose_tail(PoseTailArgs a) {
+    __shared__ int s_w[16];
+    __shared__ double s_pose[12], s_P[12];
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    int32_t* info = (int32_t*)(a.rsout + 12);
+    const int Md = min(a.capL, *a.M_dev);
+    if (tid < 12) {
+        const double* out = a.rsout;
+        const int c = tid - 9;
+        const double p = tid < 9 ? out[tid] : -((out[c] * out[9] + out[3 + c] * out[10]) + out[6 + c] * out[11]);
+        a.pose_now[tid] = p;
+        s_pose[tid] = p;
+        s_P[tid] = proj_elem(out, a.K, tid >> 2, tid & 3);
+    }
+    __syncthreads();
+    const bool solved = info[0] == 0;
+    double P[12], K[9], cam[12];
+    for (int k = 0; k < 12; ++k) P[k] = s_P[k];
+    for (int k = 0; k < 9; ++k) K[k] = a.K[k];
+    camera_matrix(s_pose, K, cam);
+    int base = 0, n_in = 0;
+    for (int i0 = 0; i0 < a.capL; i0 += 1024) {
+        const int i = i0 + tid;
+        bool in = false;
+        int f = 0;
+        if (i < Md) {
+            const double Xi[3] = {a.vl[i], a.vl[a.capL + i], a.vl[2 * a.capL + i]};
+            const double x = a.vk[i], y = a.vk[a.capL + i];
+            if (solved) {
+                const ProjT p = proj_terms(P, Xi[0], Xi[1], Xi[2], x, y);
+                in = p.ez < a.thr2 * p.z2;
+            }
+            double u, v, w;
+            project(cam, Xi, u, v, w);
+            const double du = x - u, dv = y - v;
+            const double e = sqrt(du * du + dv * dv);
+            a.err[i] = e;
+            f = e < a.kop.thr ? 1 : 0;
+        }
+        if (i < a.capL) a.inl[i] = in ? 1 : 0;
+        const unsigned long long bal = __ballot(in);
+        if ((tid & 63) == 0) n_in += __popcll(bal);
+        int tot;
+        const int pos = block_excl_scan_1024(f, &tot, s_w);
+        if (f) a.kop.move(i, base + pos);
+        base += tot;
+    }
+    if ((tid & 63) == 0 && n_in) atomicAdd(&info[4], n_in);
+    if (tid == 0) *a.count = base;
+}
+
 // :106-113, :130: 0 drop, 1 promote (angle large), 2 keep as candidate (angle small, young enough)
 struct ClassifyArgs {
     const uint8_t *tracked, *ok; const double *rep, *ang; const int32_t* ctime; double max_rep, ang_thr; int recall;
@@ -147,7 +209,7 @@ struct MergeArgs {
     ClassifyArgs c;                 // which candidates are promotable (class 1)
 };
 constexpr int MERGE_LDS = 4096;       // pool entries (landmarks + promotable candidates) of the one-block form
-constexpr int MERGE_ONE_BLOCK = 768;  // landmarks + candidates up to which the single block is the fastest form
+constexpr int MERGE_ONE_BLOCK = 1280; // landmarks + candidates up to which the single block is the fastest form
 
 // No sequential loop: at the cap every accepted candidate evicts the current
 // first maximum, so the landmark set is a streaming "cap smallest so far": the maximum never grows, an
@@ -181,17 +243,37 @@ __global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a) {
     const int P = n0 + np;                 // <= PW <= MERGE_LDS (checked by the host)
     for (int e = tid; e < P; e += 1024) s_v[e] = e < n0 ? a.wrep[e] : a.crep[s_pidx[e - n0]];
     __syncthreads();
-    for (int e = tid; e < P; e += 1024) {
-        const double ve = s_v[e];
-        int rank = 0, before = 0;
-        for (int x = 0; x < P; ++x) {
-            const double vx = s_v[x];
-            const int less = vx < ve;
-            rank += less | ((vx == ve) & (x > e));
-            before += less & (x < e);
+    // 16 lanes per element, 64 elements per round: a pool of a few hundred entries keeps the whole block busy
+    // (one thread per element left most of it idle while the busy threads walked the whole pool)
+    const int slice = tid & 15, eg = tid >> 4;
+    for (int e0 = 0; e0 < P; e0 += 64) {
+        const int e = e0 + eg;
+        const bool live = e < P;
+        const double ve = live ? s_v[e] : 0.0;
+        // before = #{x < e : v_x < v_e};  rank = before + #{x > e : v_x <= v_e}: one compare and one add per pair
+        int before = 0, after = 0;
+        // (four independent LDS reads per step: one read per step made the loop a chain of LDS latencies)
+        if (live) {
+            int x = slice;
+            for (; x + 48 < e; x += 64) {
+                const double v0 = s_v[x], v1 = s_v[x + 16], v2 = s_v[x + 32], v3 = s_v[x + 48];
+                before += (int)(v0 < ve) + (int)(v1 < ve) + (int)(v2 < ve) + (int)(v3 < ve);
+            }
+            for (; x < e; x += 16) before += s_v[x] < ve;
+            if (x == e) x += 16;
+            for (; x + 48 < P; x += 64) {
+                const double v0 = s_v[x], v1 = s_v[x + 16], v2 = s_v[x + 32], v3 = s_v[x + 48];
+                after += (int)(v0 <= ve) + (int)(v1 <= ve) + (int)(v2 <= ve) + (int)(v3 <= ve);
+            }
+            for (; x < P; x += 16) after += s_v[x] <= ve;
         }
-        s_surv[e] = rank < a.cap;
-        s_acc[e] = before < a.cap;         // meaningful for candidates (e >= n0)
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) { before += __shfl_xor(before, d, 64); after += __shfl_xor(after, d, 64); }
+        const int rank = before + after;
+        if (live && slice == 0) {
+            s_surv[e] = rank < a.cap;
+            s_acc[e] = before < a.cap;     // meaningful for candidates (e >= n0)
+        }
     }
     __syncthreads();
     // accepted candidates, in order, become work-array entries n0, n0 + 1, ...
@@ -296,7 +378,7 @@ __global__ __launch_bounds__(1024) void k_merge_write(MergeWideArgs w) {
 // ... and the sizes of the state the NEXT frame starts from
 __global__ void k_append_new(int32_t* counts, int capL, int capC, const float* su, const float* sv, int pose_slot, double* cu,
                              double* cf, int32_t* cpose, int32_t* ctime, const double* rsout, const double* pose_now,
-                             double* packed, int32_t* sizes) {
+                             double* rec, int32_t* sizes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int nC = counts[1];
     int m = counts[2];
@@ -310,13 +392,25 @@ __global__ void k_append_new(int32_t* counts, int capL, int capC, const float* s
     }
     if (i == 0) {
         counts[3] = nC + take; counts[4] = m > room ? 1 : 0; counts[5] = take;
-        for (int k = 0; k < 16; ++k) packed[k] = rsout[k];
-        for (int k = 0; k < 12; ++k) packed[16 + k] = pose_now[k];
-        int32_t* pc = (int32_t*)(packed + 28);
-        for (int k = 0; k < 16; ++k) pc[k] = k == 3 ? nC + take : (k == 4 ? (m > room ? 1 : 0) : (k == 5 ? take : counts[k]));
         sizes[1] = nC + take;   // (sizes[0], the landmarks, was written by k_compact2: the next frame's landmark branch starts there)
     }
+    // the record, straight into the pinned host slot (36 lanes of the first block, one word each: no copy command
+    // behind the frame's last kernel)
+    if (i < 28) rec[i] = i < 16 ? rsout[i] : pose_now[i - 16];
+    else if (i < 36) {
+        int32_t pc[2];
+        for (int j = 0; j < 2; ++j) {
+            const int k = 2 * (i - 28) + j;
+            pc[j] = k == 3 ? nC + take : (k == 4 ? (m > room ? 1 : 0) : (k == 5 ? take : counts[k]));
+        }
+        int32_t* out = (int32_t*)(rec + i);
+        out[0] = pc[0]; out[1] = pc[1];
+    }
 }
+
+// diagnosis (VO_FRAME_STAMPS): the constant 100 MHz device clock at a point of a stream, written to pinned host memory
+__global__ void k_stamp(long long* p) { *p = wall_clock64(); }
+constexpr int STAMP_FRAMES = 4096, STAMP_N = 16;
 
 } // namespace
 
@@ -333,7 +427,7 @@ struct vo_frame_state {
     const uint8_t* ahead_src = nullptr; int ahead_on_device = 0;  // issued into slot (cur + 1) % 3
     uint64_t ahead_gen = 0;                 // hand-out number of the selection work area it used (vo_ctx::sel_gen)
     hipEvent_t ev_ready = nullptr;          // side stream: copy + pyramid of the look-ahead slot
-    hipEvent_t ev_fork_la = nullptr;        // ctx stream: behind the tracking launch
+    hipEvent_t ev_fork_la = nullptr;        // ctx stream: in front of the frame's candidate track
     hipEvent_t ev_detect[2] = {nullptr, nullptr};  // side stream: detect half, per selection work set (frame parity)
     vo_sel_work selw[2];
     bool have_prev;
@@ -356,10 +450,12 @@ struct vo_frame_state {
     // two branches of a frame (vo_frame_submit): the landmark branch on the ctx's lane stream, the rest on the ctx stream
     hipEvent_t ev_state = nullptr;          // ctx stream: the next state's landmarks are in place (k_compact2)
     hipEvent_t ev_pose = nullptr;           // lane: pose, reprojection filter and its compaction are done
-    hipEvent_t ev_fork_lane = nullptr;      // lane: behind the landmarks' tracking launch (look-ahead)
     bool state_event = false;               // ev_state stands for the current state (false after set_state / set_image)
     bool overlap = true;                    // VO_FRAME_SERIAL=1: both branches on the ctx stream
     hipEvent_t ev_rec[VO_FRAME_MAX_PENDING] = {};
+    long long* h_stamps = nullptr;          // VO_FRAME_STAMPS=<file>: device clock at 16 points of each frame (diagnosis only)
+    std::string stamp_path;
+    unsigned stamp_mask = 0xffffu;          // VO_FRAME_STAMP_MASK: which of the points (every stamp is a launch of its own)
     int pend_frame_no[VO_FRAME_MAX_PENDING] = {};
     int pend_head = 0, pend_count = 0;
 };
@@ -451,8 +547,13 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_fork_la, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_state, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_pose, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_fork_lane, hipEventDisableTiming);
     st->overlap = !getenv("VO_FRAME_SERIAL");
+    if (const char* sp = getenv("VO_FRAME_STAMPS")) {
+        st->stamp_path = sp;
+        if (const char* mk = getenv("VO_FRAME_STAMP_MASK")) st->stamp_mask = (unsigned)strtoul(mk, nullptr, 0);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_stamps, (size_t)STAMP_FRAMES * STAMP_N * sizeof(long long), 0);
+        if (e == hipSuccess) memset(st->h_stamps, 0, (size_t)STAMP_FRAMES * STAMP_N * sizeof(long long));
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_counts, 16 * sizeof(int32_t), 0);
@@ -485,11 +586,25 @@ int vo_frame_destroy(vo_ctx* ctx, vo_frame_state* st) {
     if (st->ev_fork_la) (void)hipEventDestroy(st->ev_fork_la);
     if (st->ev_state) (void)hipEventDestroy(st->ev_state);
     if (st->ev_pose) (void)hipEventDestroy(st->ev_pose);
-    if (st->ev_fork_lane) (void)hipEventDestroy(st->ev_fork_lane);
     for (int k = 0; k < 2; ++k) if (st->ev_detect[k]) (void)hipEventDestroy(st->ev_detect[k]);
     for (int k = 0; k < VO_FRAME_MAX_PENDING; ++k) if (st->ev_rec[k]) (void)hipEventDestroy(st->ev_rec[k]);
     if (st->h_counts) (void)hipHostFree(st->h_counts);
     if (st->h_rec) (void)hipHostFree(st->h_rec);
+    if (st->h_stamps) {
+        if (FILE* fp = fopen(st->stamp_path.c_str(), "w")) {
+            for (int f = 0; f < STAMP_FRAMES; ++f) {
+                const long long* r = st->h_stamps + (size_t)f * STAMP_N;
+                bool any = false;
+                for (int k = 0; k < STAMP_N; ++k) any = any || r[k];
+                if (!any) continue;
+                fprintf(fp, "%d", f);
+                for (int k = 0; k < STAMP_N; ++k) fprintf(fp, " %lld", r[k]);
+                fprintf(fp, "\n");
+            }
+            fclose(fp);
+        }
+        (void)hipHostFree(st->h_stamps);
+    }
     delete st;
     return VO_OK;
 }
@@ -650,8 +765,13 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     // stand-alone vo_select_candidates): then it is abandoned like a wrong announcement
     const bool ahead = st->ahead_src && st->ahead_src == img && st->ahead_on_device == on_device &&
                        (o.sel.keep <= 0 || ctx->sel_gen[set] == st->ahead_gen);
+    bool detect_joined = false;      // the ctx stream already waits for this frame's detect half
     if (ahead) {
-        ST_CHECK(hipStreamWaitEvent(sm, st->ev_ready, 0));
+        // the side stream ran copy, pyramid (ev_ready), detect half (ev_detect) in that order: one wait of the ctx
+        // stream for the later event covers both (every wait in the chain of a frame costs 5-10 us of its own, even
+        // when long satisfied); the landmark branch needs the pyramid only
+        if (o.sel.keep > 0) { ST_CHECK(hipStreamWaitEvent(sm, st->ev_detect[set], 0)); detect_joined = true; }
+        else ST_CHECK(hipStreamWaitEvent(sm, st->ev_ready, 0));
         if (sl != sm) ST_CHECK(hipStreamWaitEvent(sl, st->ev_ready, 0));
         st->ahead_src = nullptr;
     } else {
@@ -679,16 +799,21 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         ctx->stream = sl; ctx->in_lane = true;           // the launchers below enqueue on ctx->stream
     }
     auto leave_lane = [&]() { ctx->stream = sm; ctx->in_lane = false; };
+    auto stamp = [&](hipStream_t q, int id) {
+        if (st->h_stamps && frame_no < STAMP_FRAMES && ((st->stamp_mask >> id) & 1)) hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, q, st->h_stamps + (size_t)frame_no * STAMP_N + id);
+    };
+    stamp(sl, 0);
     // [1] :278-281 track the landmarks' keypoints (read straight from the state) and keep the validly tracked ones in
     // order.  The number M of those stays on the device (counts[6]): the pose step, the reprojection filter and the
     // compaction are sized by the capacity and read M themselves.
     if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->kp[s], st->kp[s] + cl, cl, o.klt.block_w, o.klt.block_h,
                             o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, st->score, nullptr, st->sizes + 0))) { leave_lane(); return rc; }
-    if (st->next_src && sl != sm && hipEventRecord(st->ev_fork_lane, sl) != hipSuccess) { leave_lane(); ctx->last_error = "frame: hipEventRecord failed"; return VO_ERR_HIP; }
+    stamp(sl, 1);
     {   // (the frame's counters and tombstones are cleared by the same launch)
         TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
         hipLaunchKernelGGL(k_tracked, dim3(1), dim3(1024), 0, sl, counts, st->alive, pw, top, cl, st->sizes + 0);
     }
+    stamp(sl, 2);
     // [2] :285-289 pose (fewer than 4 tracked points: k_best gives status 1 and the identity, as the toolbox function errors out)
     {
         vo_ransac_opts ro = o.pose;
@@ -696,29 +821,38 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         vo_ransac_work w;
         if ((rc = vo_int_ransac_work_prepare(ctx, ro.num_hyp, &w))) { leave_lane(); return rc; }
         vo_strides s2 = {1, cl}, s3 = {1, cl};
-        if ((rc = vo_launch_ransac(ctx, st->vk, s2, st->vl, s3, cl, st->K, &ro, nullptr, nullptr, &w, rsout, st->inl, counts + 6, 0,
-                                   pose_now))) { leave_lane(); return rc; }   // the pose step's last kernel also writes the pose (:318)
+        if ((rc = vo_launch_ransac(ctx, st->vk, s2, st->vl, s3, cl, st->K, &ro, nullptr, nullptr, &w, rsout, nullptr, counts + 6, 0,
+                                   nullptr))) { leave_lane(); return rc; }   // (no inlier flags asked for: k_pose_tail below ends the pose step)
+        stamp(sl, 3);
+        // [3] :298-315 the record's pose and inliers, reprojection error, strict filter, survivors into the merge arrays
+        PoseTailArgs pt;
+        pt.vk = st->vk; pt.vl = st->vl; pt.capL = cl; pt.M_dev = counts + 6; pt.K = st->K;
+        pt.thr2 = ro.max_reproj_err * ro.max_reproj_err; pt.rsout = rsout; pt.inl = st->inl; pt.pose_now = pose_now; pt.err = st->err;
+        pt.kop = KeptOp{st->err, o.max_reproj_err, st->vk, st->vl, cl, pw, st->wkp, st->wL, st->wrep, st->alive};
+        pt.count = counts + 7;
+        hipLaunchKernelGGL(k_pose_tail, dim3(1), dim3(1024), 0, sl, pt);
     }
-    // [3] :298-315 reprojection error, strict filter, survivors into the merge arrays
-    {
-        vo_strides s2 = {1, cl}, s3 = {1, cl};
-        if ((rc = vo_launch_reproj(ctx, st->vk, s2, st->vl, s3, cl, pose_now, 0, st->K, st->err, counts + 6))) { leave_lane(); return rc; }
-        KeptOp kop = {st->err, o.max_reproj_err, st->vk, st->vl, cl, pw, st->wkp, st->wL, st->wrep, st->alive};
-        hipLaunchKernelGGL(k_compact<KeptOp>, dim3(1), dim3(1024), 0, sl, kop, cl, counts + 7, counts + 6);
-    }
+    stamp(sl, 4);
     if (sl != sm) {
         leave_lane();
         ST_CHECK(hipEventRecord(st->ev_pose, sl));
     }
 
     // ---- candidate branch and the rest, on the ctx stream ----
+    // look-ahead, part 1: the point of the ctx stream behind which the side stream may start.  The look-ahead
+    // overwrites the image slot that held the PREVIOUS frame's first image -- last read by that frame's two tracking
+    // launches, both finished before its triangulation -- and the selection work area of the previous frame, whose
+    // filter ran on this stream: everything it must not overtake lies behind this point.  (It used to start behind
+    // this frame's tracking launches and then ran beside the selection filter and the next landmark track, all of
+    // them single chains of dependent instructions that slow each other down on a shared SIMD.)
+    if (st->next_src) ST_CHECK(hipEventRecord(st->ev_fork_la, sm));
+    stamp(sm, 5);
     // :71 track the candidates: points from the state, results straight into the candidates' work arrays
     if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->cu[s], st->cu[s] + cc, cc, o.klt.block_w, o.klt.block_h,
                             o.klt.max_iters, eps, o.klt.max_bidir_err, st->cq, st->cq + cc, st->cvalid, st->score + cl, nullptr, st->sizes + 1))) return rc;
-    // look-ahead, part 1: the points of the two streams behind which the side stream may start (the tracking launches
-    // are the last readers of the slot and of the work area that the look-ahead overwrites)
-    if (st->next_src) ST_CHECK(hipEventRecord(st->ev_fork_la, sm));
+    stamp(sm, 6);
     if (sl != sm) ST_CHECK(hipStreamWaitEvent(sm, st->ev_pose, 0));
+    stamp(sm, 7);
     // [4] :322 -> :63-151 triangulate the tracked candidates, classify, merge in candidate order
     {
         vo_strides c2 = {1, cc}, c3 = {1, cc};
@@ -747,22 +881,30 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         hipLaunchKernelGGL((k_compact2<CandOp, LandmarkOp>), dim3(2), dim3(1024), 0, sm, cop, cc, counts + 1, st->sizes + 1, lop, pw, counts + 0,
                            st->sizes + 0, cl);
     }
-    ST_CHECK(hipEventRecord(st->ev_state, sm));   // the next frame's landmark branch may start here
+    stamp(sm, 8);
+    // The next frame's landmark branch may start here -- one launch later when there is a selection: its k_uniform is
+    // one block of 16 waves with 127 registers, which needs a compute unit to itself, and the landmark track puts a
+    // wave on every one of them.  Released at the same moment the track won that race and the block waited for the
+    // track's waves to end (45 -> 60-90 us on the ctx stream's chain); released behind k_kill (5 us), the block,
+    // next in its stream, is placed before the other stream's wait has even been seen.
+    if (o.sel.keep <= 0) ST_CHECK(hipEventRecord(st->ev_state, sm));
     // [5b] :330-345 new candidates away from every tracked point; the number of existing points stays on the
     // device (counts[0] + counts[1]), so the host does not wait here
     // (the single cast of [keypoints; candidate_keypoints], :330-331, happens inside the filter's kernel)
     if (o.sel.keep > 0) {
-        ST_CHECK(hipStreamWaitEvent(sm, st->ev_detect[set], 0));
+        if (!detect_joined) ST_CHECK(hipStreamWaitEvent(sm, st->ev_detect[set], 0));
+        stamp(sm, 9);
         if ((rc = vo_launch_select_filter(ctx, sm, st->nu, st->nv, 0, nullptr, nullptr, cl + cc, counts, &o.sel, &selw, st->su, st->sv,
-                                          st->slin, nullptr, counts + 2, st->kp[n], cl, st->cu[n], cc))) return rc;
+                                          st->slin, nullptr, counts + 2, st->kp[n], cl, st->cu[n], cc, st->ev_state))) return rc;
     }
+    stamp(sm, 10);
+    const int ps = (st->pend_head + st->pend_count) % VO_FRAME_MAX_PENDING;
     hipLaunchKernelGGL(k_append_new, dim3(blocks(std::max(o.sel.keep, 1))), dim3(256), 0, sm, counts, cl, cc, st->su, st->sv, slot,
-                       st->cu[n], st->cf[n], st->cpose[n], st->ctime[n], rsout, pose_now, st->packed, st->sizes);
+                       st->cu[n], st->cf[n], st->cpose[n], st->ctime[n], rsout, pose_now, st->h_rec + 40 * (size_t)ps, st->sizes);
     // the frame's record into the next pinned slot; whoever collects the frame waits for the slot's event only
     // (enqueued before the look-ahead's dozen launches: the record is not held up behind host work it does not need)
-    const int ps = (st->pend_head + st->pend_count) % VO_FRAME_MAX_PENDING;
-    ST_CHECK(hipMemcpyAsync(st->h_rec + 40 * (size_t)ps, st->packed, 36 * sizeof(double), hipMemcpyDeviceToHost, sm));
     ST_CHECK(hipEventRecord(st->ev_rec[ps], sm));
+    stamp(sm, 11);
     st->pend_frame_no[ps] = frame_no;
     ++st->pend_count;
     st->s = n; st->cur = b; st->frame_no = frame_no;   // the frame is in: what follows is work for the next one
@@ -777,14 +919,16 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         if ((rc = vo_int_frame_prepare(ctx, &st->pyr[c], st->nu, st->nv, o.klt.levels))) return rc;   // may grow (first use)
         if ((rc = vo_int_side_ensure(ctx))) return rc;
         ST_CHECK(hipStreamWaitEvent(ctx->side, st->ev_fork_la, 0));   // long satisfied by the time this is enqueued
-        if (sl != sm) ST_CHECK(hipStreamWaitEvent(ctx->side, st->ev_fork_lane, 0));
+        stamp(ctx->side, 12);
         if ((rc = copy_image(ctx, st, c, st->next_src, st->next_on_device, ctx->side))) return rc;
         if ((rc = build_pyramid(ctx, st, c, ctx->side))) return rc;
+        stamp(ctx->side, 13);
         ST_CHECK(hipEventRecord(st->ev_ready, ctx->side));
         if (o.sel.keep > 0) {
             if ((rc = vo_launch_select_detect(ctx, ctx->side, st->img[c], st->nu, st->nv, &o.sel, &nw))) return rc;
             ST_CHECK(hipEventRecord(st->ev_detect[1 - set], ctx->side));
         }
+        stamp(ctx->side, 14);
         st->ahead_src = st->next_src; st->ahead_on_device = st->next_on_device; st->ahead_gen = ctx->sel_gen[1 - set];
         st->next_src = nullptr;
     }

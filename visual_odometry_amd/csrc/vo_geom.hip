@@ -6,30 +6,11 @@
 //
 // Bound: ~60 algorithmic bytes and ~1.5 kflop (FP64) per candidate: launch-latency / HBM bound.
 #include "vo_common.h"
+#include "vo_dev_math.h"
 
 namespace {
 
 struct M43 { double m[12]; }; // 4x3 row-major
-
-__device__ __forceinline__ void load43(const double* p, int col_major, double* out) {
-    if (col_major) {
-        for (int r = 0; r < 4; ++r)
-            for (int c = 0; c < 3; ++c) out[r * 3 + c] = p[c * 4 + r];
-    } else {
-        for (int k = 0; k < 12; ++k) out[k] = p[k];
-    }
-}
-
-__device__ __forceinline__ void camera_matrix(const double* pose, const double* K, double* cam) {
-    double E[12];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) E[i * 3 + j] = pose[j * 3 + i];
-    for (int j = 0; j < 3; ++j)
-        E[9 + j] = -((pose[9] * pose[j * 3 + 0] + pose[10] * pose[j * 3 + 1]) + pose[11] * pose[j * 3 + 2]);
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 3; ++j)
-            cam[i * 3 + j] = (E[i * 3 + 0] * K[j * 3 + 0] + E[i * 3 + 1] * K[j * 3 + 1]) + E[i * 3 + 2] * K[j * 3 + 2];
-}
 
 __device__ __forceinline__ double angle_deg(const double* X, const double* c0, const double* c1) {
     double a[3], b[3];
@@ -41,13 +22,6 @@ __device__ __forceinline__ double angle_deg(const double* X, const double* c0, c
     if (c > 1.0) c = 1.0;
     if (c < -1.0) c = -1.0;
     return acos(c) * (180.0 / 3.14159265358979323846);
-}
-
-__device__ __forceinline__ void project(const double* cam, const double* X, double& u, double& v, double& w) {
-    double pu = ((X[0] * cam[0] + X[1] * cam[3]) + X[2] * cam[6]) + cam[9];
-    double pv = ((X[0] * cam[1] + X[1] * cam[4]) + X[2] * cam[7]) + cam[10];
-    double pw = ((X[0] * cam[2] + X[1] * cam[5]) + X[2] * cam[8]) + cam[11];
-    u = pu / pw; v = pv / pw; w = pw;
 }
 
 // One-sided Jacobi as oracle/geom.c svd4_last defines it: a sweep is three rounds of two disjoint column pairs,

@@ -19,6 +19,7 @@
 // All arithmetic is IEEE double in the oracle's operation order (-ffp-contract=off).
 // Bound: FP64 VALU (two IEEE divisions per pose x point); points and poses are L2/LDS resident.
 #include "vo_common.h"
+#include "vo_dev_math.h"
 
 namespace {
 
@@ -305,28 +306,6 @@ __global__ __launch_bounds__(64, 4) void k_hyp(HypArgs a) {   // <= 128 VGPRs: f
         for (int k = 0; k < 9; ++k) o[k] = R[k];
         for (int k = 0; k < 3; ++k) o[9 + k] = t[k];
     }
-}
-
-// Scoring arithmetic (oracle/vo_oracle.h N9).  Each pose is folded once into the 3x4 projection
-// Pm = K [R_cw | t_cw]; the projection is kept homogeneous, so the inlier test needs no division:
-//   ez = (u*z - u~)^2 + (v*z - v~)^2 < thr^2 * z^2,
-// with explicit fused multiply-adds in a fixed order.  Only inliers pay for e2 = ez / z^2 (MSAC term).
-__device__ __forceinline__ double proj_elem(const double* Rt, const double* K, int r, int c) {
-    const double g0 = c < 3 ? Rt[c] : Rt[9], g1 = c < 3 ? Rt[3 + c] : Rt[10], g2 = c < 3 ? Rt[6 + c] : Rt[11];
-    if (r == 0) return fma(K[2], g2, fma(K[1], g1, K[0] * g0));
-    if (r == 1) return fma(K[5], g2, K[4] * g1);
-    return g2;
-}
-struct ProjT { double ez, z2; };
-__device__ __forceinline__ ProjT proj_terms(const double* P, double X0, double X1, double X2, double u, double v) {
-    const double up = fma(P[2], X2, fma(P[1], X1, fma(P[0], X0, P[3])));
-    const double vp = fma(P[6], X2, fma(P[5], X1, fma(P[4], X0, P[7])));
-    const double zc = fma(P[10], X2, fma(P[9], X1, fma(P[8], X0, P[11])));
-    const double du = fma(u, zc, -up), dv = fma(v, zc, -vp);
-    ProjT r;
-    r.ez = fma(dv, dv, du * du);
-    r.z2 = zc * zc;
-    return r;
 }
 
 constexpr int SC_HB = 2;          // hypotheses per block
@@ -784,6 +763,10 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
         hipLaunchKernelGGL(k_survivors, dim3((4 * (H - S) + 63) / 64), dim3(64), 0, ctx->stream, sv);
         score(S, H, 2, 3, true, 2, true);                     // what is left on the rest
         best(H, 1, false);
+    }
+    if (!d_inliers) {      // the caller's next launch does what k_inliers does (the frame loop: k_pose_tail)
+        VO_HIP_CHECK(ctx, hipGetLastError());
+        return VO_OK;
     }
     InlArgs in;
     in.xy = d_xy; in.sxy = sxy; in.X = d_X; in.sX = sX; in.M = M; in.K = d_K; in.thr2 = thr2; in.out = (double*)d_out;

@@ -911,7 +911,7 @@ int vo_launch_select_detect(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_im
 int vo_launch_select_filter(vo_ctx* ctx, hipStream_t stream, int nu, int nv, int u_is_rows, const float* d_eu,
                             const float* d_ev, int n_exist, const int32_t* ne_dev, const vo_sel_opts* o, vo_sel_work* w,
                             float* d_out_u, float* d_out_v, int32_t* d_out_lin, double* d_out_metric,
-                            int32_t* d_out_count, const double* d_kpL, int capL, const double* d_cuC, int capC) {
+                            int32_t* d_out_count, const double* d_kpL, int capL, const double* d_cuC, int capC, hipEvent_t after_kill) {
     if (o->keep < 0 || n_exist < 0) { ctx->last_error = "select: negative count"; return VO_ERR_BAD_ARG; }
     if (d_kpL && (!ne_dev || !d_cuC)) { ctx->last_error = "select: the state form of the existing points needs device counts"; return VO_ERR_BAD_ARG; }
     const float thr_d2 = d2_threshold((float)o->min_distance);
@@ -919,6 +919,7 @@ int vo_launch_select_filter(vo_ctx* ctx, hipStream_t stream, int nu, int nv, int
         const ExistSrc src = {d_eu, d_ev, d_kpL, d_cuC, capL, capC};
         hipLaunchKernelGGL(k_kill, dim3((n_exist + 63) / 64, 3), dim3(64), 0, stream, src, n_exist, ne_dev, grid_args(w), thr_d2, w->keep);
     }
+    if (after_kill) VO_HIP_CHECK(ctx, hipEventRecord(after_kill, stream));
     UniArgs a;
     a.cu = w->lu; a.cv = w->lv; a.metric = w->metric; a.lin = w->lin; a.keep = w->keep; a.sel = w->sel; a.m0 = w->m0;
     a.n_keep = o->keep; a.nu = nu; a.nv = nv; a.u_is_rows = u_is_rows;
