@@ -477,16 +477,23 @@ def test_process_frame_runs_on_a_synthetic_scene(ctx):
     assert status3 == 0 and (st3.candidate_time_indxs <= -1).all()
 
 
+@pytest.mark.parametrize("m", [1500, 300, 1024, 37])
 @pytest.mark.parametrize("outlier_frac,mode", [(0.2, 1), (0.75, 0), (0.75, 1), (0.93, 1)])
-def test_ransac_adaptive_run_in_two_stages(ctx, outlier_frac, mode):
+def test_ransac_adaptive_run_in_two_stages(ctx, outlier_frac, mode, m):
     """With a confidence and more than 512 hypotheses the launcher scores the first 256 first and the rest only
     if the sequential stop was not reached among them: the stop inside the first stage (20 % outliers), beyond it
-    (75 %: about 290 trials) and never (93 %) all give the oracle's trial count, best hypothesis and inlier set."""
-    xy, X, *_ = synth.pnp_scene(1500, seed=77, outlier_frac=outlier_frac)
+    (75 %: about 290 trials) and never (93 %) all give the oracle's trial count, best hypothesis and inlier set.
+    Up to 1024 points a stage is ONE launch (k_pose_small: each block generates and scores its own hypotheses, the
+    last one to finish scans); above, three."""
+    xy, X, *_ = synth.pnp_scene(m, seed=77, outlier_frac=outlier_frac)
     a = ops.p3p_ransac(xy, X, K, num_hyp=2000, max_reproj_err=2.0, confidence=0.99, seed=11, mode=mode, min_inliers=4)
     b = oracle.p3p_ransac(xy, X, K, num_hyp=2000, max_reproj=2.0, confidence=0.99, seed=11, mode=mode, min_inliers=4, threads=8)
-    assert a["trials"] == b["trials"] and a["status"] == b["status"] == 0
-    assert (a["trials"] < 256) if outlier_frac == 0.2 else (a["trials"] > 256)
+    assert a["trials"] == b["trials"] and a["status"] == b["status"]
+    if m >= 300:
+        assert a["status"] == 0
+        assert (a["trials"] < 256) if outlier_frac == 0.2 else (a["trials"] > 256)
+    else:                      # 37 points: with 93 % outliers there are fewer inliers than a model needs (status 2)
+        assert a["status"] == (2 if outlier_frac > 0.9 else 0)
     assert (a["best_hyp"], a["best_sol"]) == (b["best_hyp"], b["best_sol"])
     np.testing.assert_array_equal(a["inliers"], b["inliers"])
     np.testing.assert_allclose(a["R"], b["R"], rtol=1e-9, atol=1e-12)

@@ -138,6 +138,7 @@ struct vo_ransac_work {
     // cnt | cost | {bound[2], list_n} are one contiguous block of zero_bytes bytes, zeroed at the start of a run
     // (k_score adds into cnt / cost); list: pose ids that survive the first quarter of the points (k_survivors)
     unsigned long long* bound = nullptr; int32_t* list_n = nullptr; int32_t* list = nullptr; size_t zero_bytes = 0;
+    int32_t* ticket = nullptr;   // one int that is zero between launches (k_pose_small); null: that form is not used
 };
 int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int M,
                      const double* d_K, const vo_ransac_opts* o, const int32_t* d_sample_idx,

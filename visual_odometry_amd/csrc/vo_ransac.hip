@@ -265,25 +265,15 @@ struct HypArgs {
 // 12 us alone, 240 us beside k_lk).  A raised wave priority lets these short kernels through.
 #define VO_POSE_PRIO() __builtin_amdgcn_s_setprio(3)
 
-__global__ __launch_bounds__(64, 4) void k_hyp(HypArgs a) {   // <= 128 VGPRs: fits the hole one finished tracking wave leaves (160 did not: the kernel starved beside k_lk)
-    VO_POSE_PRIO();
-    const int h = a.h0 + blockIdx.x * 64 + threadIdx.x;
-    if (h >= a.H || (a.stopped && *a.stopped)) return;
-    if (a.zcnt) {
-        *reinterpret_cast<int4*>(a.zcnt + 4 * (long)h) = make_int4(0, 0, 0, 0);
-        *reinterpret_cast<ulonglong2*>(a.zcost + 4 * (long)h) = make_ulonglong2(0ull, 0ull);
-        *reinterpret_cast<ulonglong2*>(a.zcost + 4 * (long)h + 2) = make_ulonglong2(0ull, 0ull);
-        if (h == 0)
-            for (int k = 0; k < 32; ++k) a.zblock[k] = 0ull;
-    }
-    if (a.M_dev) { a.M = min(a.M, *a.M_dev); if (a.M < 4) return; }
+// one hypothesis: sample, P3P, the four solutions as [R_cw | t_cw] into a.Rt (and into `lds`, 48 doubles, if given)
+__device__ __forceinline__ void hyp_body(const HypArgs& a, int M, int h, double* lds) {
     double K[9];
     for (int k = 0; k < 9; ++k) K[k] = a.K[k];
     int32_t id[3];
     bool ok = true;
     if (a.sample_idx) {
-        for (int k = 0; k < 3; ++k) { id[k] = a.sample_idx[3 * h + k]; if (id[k] < 0 || id[k] >= a.M) ok = false; }
-    } else philox_sample3(a.seed, (uint32_t)h, (uint32_t)a.M, id);
+        for (int k = 0; k < 3; ++k) { id[k] = a.sample_idx[3 * h + k]; if (id[k] < 0 || id[k] >= M) ok = false; }
+    } else philox_sample3(a.seed, (uint32_t)h, (uint32_t)M, id);
     double poses[48];
     if (ok) {
         double Pw[9], f[9];
@@ -305,7 +295,26 @@ __global__ __launch_bounds__(64, 4) void k_hyp(HypArgs a) {   // <= 128 VGPRs: f
         double* o = a.Rt + 48 * (long)h + 12 * s;
         for (int k = 0; k < 9; ++k) o[k] = R[k];
         for (int k = 0; k < 3; ++k) o[9 + k] = t[k];
+        if (lds) {
+            for (int k = 0; k < 9; ++k) lds[12 * s + k] = R[k];
+            for (int k = 0; k < 3; ++k) lds[12 * s + 9 + k] = t[k];
+        }
     }
+}
+
+__global__ __launch_bounds__(64, 4) void k_hyp(HypArgs a) {   // <= 128 VGPRs: fits the hole one finished tracking wave leaves (160 did not: the kernel starved beside k_lk)
+    VO_POSE_PRIO();
+    const int h = a.h0 + blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.H || (a.stopped && *a.stopped)) return;
+    if (a.zcnt) {
+        *reinterpret_cast<int4*>(a.zcnt + 4 * (long)h) = make_int4(0, 0, 0, 0);
+        *reinterpret_cast<ulonglong2*>(a.zcost + 4 * (long)h) = make_ulonglong2(0ull, 0ull);
+        *reinterpret_cast<ulonglong2*>(a.zcost + 4 * (long)h + 2) = make_ulonglong2(0ull, 0ull);
+        if (h == 0)
+            for (int k = 0; k < 32; ++k) a.zblock[k] = 0ull;
+    }
+    if (a.M_dev) { a.M = min(a.M, *a.M_dev); if (a.M < 4) return; }
+    hyp_body(a, a.M, h, nullptr);
 }
 
 constexpr int SC_HB = 2;          // hypotheses per block
@@ -337,11 +346,11 @@ __device__ __forceinline__ int sieve_mark(const int32_t* qdev, int q) {
     if (!qdev) return q;
     return q <= 0 ? 0 : (q == 1 ? qdev[0] : (q == 2 ? qdev[1] : 64));
 }
-__global__ __launch_bounds__(SC_NT) void k_score(ScoreArgs a) {
-    VO_POSE_PRIO();
+// the body of k_score.  own_poses (k_pose_small): the block's eight poses lie in LDS (the block generated them itself)
+// and the block sees every point, so its sums are stored, not added
+__device__ __forceinline__ void score_body(ScoreArgs a, const double* own_poses) {
     __shared__ double sRt[SC_NS * 12];
     __shared__ int s_pid[SC_NS];
-    if (a.stopped && *a.stopped) return;   // uniform: the whole launch has nothing to do
     if (a.M_dev) { a.M = min(a.M, *a.M_dev); if (a.M < 4) return; }
     const int tid = threadIdx.x;
     const int nlist = a.list ? *a.list_n : 0;
@@ -357,7 +366,8 @@ __global__ __launch_bounds__(SC_NT) void k_score(ScoreArgs a) {
         const int hs = k / 12;               // pose within the block
         const int e = k - 12 * hs;           // element of the pose's 3x4 projection
         const int pid = s_pid[hs];
-        sRt[k] = pid >= 0 ? proj_elem(a.Rt + 12 * (long)pid, a.K, e >> 2, e & 3) : 0.0;
+        const double* Rt = own_poses ? own_poses + 12 * hs : a.Rt + 12 * (long)pid;
+        sRt[k] = pid >= 0 ? proj_elem(Rt, a.K, e >> 2, e & 3) : 0.0;
     }
     __syncthreads();
     const long r0 = (long)a.M * sieve_mark(a.qdev, a.q0) / 64, r1 = (long)a.M * sieve_mark(a.qdev, a.q1) / 64;
@@ -413,12 +423,21 @@ __global__ __launch_bounds__(SC_NT) void k_score(ScoreArgs a) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { c += __shfl_xor(c, d, 64); q += __shfl_xor(q, d, 64); }
         if (tid == s && s_pid[s] >= 0) {
-            if (c) atomicAdd(&a.cnt[s_pid[s]], c);
-            atomicAdd(&a.cost[s_pid[s]], q + (unsigned long long)((c1 - c0) - c) * qthr);
+            const unsigned long long total = q + (unsigned long long)((c1 - c0) - c) * qthr;
+            if (own_poses) { a.cnt[s_pid[s]] = c; a.cost[s_pid[s]] = total; }
+            else {
+                if (c) atomicAdd(&a.cnt[s_pid[s]], c);
+                atomicAdd(&a.cost[s_pid[s]], total);
+            }
         }
     }
     if (tid == 0 && a.counters && !a.list && blockIdx.y == 0)
         atomicAdd(&a.counters[4 * (blockIdx.x & (VO_COUNTER_SHARDS - 1)) + 3], (unsigned long long)min(SC_HB, a.H - (a.h0 + (int)blockIdx.x * SC_HB)));
+}
+__global__ __launch_bounds__(SC_NT) void k_score(ScoreArgs a) {
+    VO_POSE_PRIO();
+    if (a.stopped && *a.stopped) return;   // uniform: the whole launch has nothing to do
+    score_body(a, nullptr);
 }
 
 // zeroes the run's sums (counts, costs, the bound and survivor-count words): one-wave blocks, see k_score
@@ -517,8 +536,7 @@ __device__ __forceinline__ BState shfl_up_state(const BState& x, int d) {
 // slots on four SIMDs at once, a one-wave workgroup takes the first hole.
 constexpr int RANSAC_STAGE = 256;  // hypotheses of the first stage of an adaptive run (a multiple of 64 and of SC_HB)
 template <int BEST_NT>
-__global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
-    VO_POSE_PRIO();
+__device__ __forceinline__ void best_body(BestArgs a) {
     __shared__ BState s_wave[BEST_NT / 64];
     __shared__ int s_stop;
     __shared__ BState s_fin;
@@ -618,6 +636,45 @@ __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
         }
         info[5] = gstop == 0x7fffffff ? 0 : 1;   // the adaptive stop was reached inside these H hypotheses
     }
+}
+template <int BEST_NT>
+__global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
+    VO_POSE_PRIO();
+    best_body<BEST_NT>(a);
+}
+
+// ---- short point sets (the frame loop: 300 landmarks): a stage of the adaptive run in ONE launch ----
+// k_hyp -> k_score -> k_best are three launches of a few microseconds of work each when the points are few, and two
+// stages make six.  Here a one-wave block generates its two hypotheses (two lanes; the P3P solve is one thread's
+// chain either way), scores their eight poses on ALL points (so its sums are stores, nothing has to be zeroed), and
+// the block that finishes last -- a ticket counted up behind a fence -- runs k_best's scan.  Same device functions,
+// same bits (test_ransac_adaptive_run_in_two_stages runs both forms against the oracle).
+struct SmallArgs { HypArgs h; ScoreArgs s; BestArgs b; int32_t* ticket; int nblocks; };
+constexpr int RANSAC_SMALL_M = 1024;   // points up to which a stage is one launch
+
+__global__ __launch_bounds__(64, 4) void k_pose_small(SmallArgs a) {
+    VO_POSE_PRIO();
+    __shared__ double s_pose[SC_HB * 48];
+    __shared__ int s_last;
+    if (a.h.stopped && *a.h.stopped) return;             // a later stage behind a stop that was reached: uniform
+    int M = a.h.M;
+    if (a.h.M_dev) M = min(M, *a.h.M_dev);
+    if (M < 4) { if (blockIdx.x == 0) best_body<64>(a.b); return; }   // status 1 and the identity (uniform per block)
+    const int tid = threadIdx.x;
+    if (tid < SC_HB) {
+        const int h = a.h.h0 + (int)blockIdx.x * SC_HB + tid;
+        if (h < a.h.H) hyp_body(a.h, M, h, s_pose + 48 * tid);
+    }
+    __syncthreads();
+    score_body(a.s, s_pose);
+    __threadfence();                                     // this block's poses and sums are out before its ticket
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(a.ticket, 1) == a.nblocks - 1;
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) *a.ticket = 0;                         // for the next launch (behind this one in its stream)
+    __threadfence();
+    best_body<64>(a.b);
 }
 
 struct InlArgs {
@@ -736,7 +793,28 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
     // little to leave out -- but the prefix first all the same: the run usually ends inside it, and the launches over
     // the other hypotheses return at once instead of generating and scoring them
     const bool prefix = !staged && H > 2 * RANSAC_STAGE && !score_all && o->confidence > 0 && !d_poses_in;
-    if (prefix) {
+    // ... and when the points are few, a stage is one launch (k_pose_small)
+    auto small_stage = [&](int h0, int h1, bool later) {
+        SmallArgs sa;
+        HypArgs& h = sa.h;
+        h.xy = d_xy; h.sxy = sxy; h.X = d_X; h.sX = sX; h.M = M; h.K = d_K; h.H = h1; h.seed = o->seed;
+        h.sample_idx = d_sample_idx; h.Rt = w->Rt; h.h0 = h0; h.stopped = later ? stopped : nullptr; h.M_dev = d_M;
+        h.zcnt = nullptr; h.zcost = nullptr; h.zblock = nullptr;
+        ScoreArgs& sc = sa.s;
+        sc.xy = d_xy; sc.sxy = sxy; sc.X = d_X; sc.sX = sX; sc.M = M; sc.K = d_K; sc.H = h1; sc.thr2 = thr2; sc.Rt = w->Rt;
+        sc.cnt = w->cnt; sc.cost = w->cost; sc.counters = ctx->d_counters; sc.h0 = h0; sc.stopped = nullptr; sc.M_dev = d_M;
+        sc.list = nullptr; sc.list_n = nullptr; sc.q0 = 0; sc.q1 = 64; sc.qdev = nullptr;
+        BestArgs& b = sa.b;
+        b.cnt = w->cnt; b.cost = w->cost; b.Rt = w->Rt; b.H = h1; b.M = M; b.mode = o->mode; b.min_inl = o->min_inliers;
+        b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 3; b.later_stage = later ? 1 : 0; b.M_dev = d_M;
+        b.bound_out = nullptr; b.sieve_out = nullptr; b.qthr = (unsigned long long)(thr2 * 1048576.0);
+        sa.ticket = w->ticket; sa.nblocks = (h1 - h0 + SC_HB - 1) / SC_HB;
+        hipLaunchKernelGGL(k_pose_small, dim3(sa.nblocks), dim3(64), 0, ctx->stream, sa);
+    };
+    if (prefix && M <= RANSAC_SMALL_M && w->ticket) {
+        small_stage(0, S, false);
+        small_stage(S, H, true);
+    } else if (prefix) {
         hyp(0, S, false);
         score(0, S, 0, 64, false, 0, false);
         best(S, 0, false);
