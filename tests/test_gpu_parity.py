@@ -499,6 +499,28 @@ def test_ransac_adaptive_run_in_two_stages(ctx, outlier_frac, mode, m):
     np.testing.assert_allclose(a["R"], b["R"], rtol=1e-9, atol=1e-12)
 
 
+def test_short_pose_runs_between_other_users_of_the_work_buffer(ctx):
+    """The pose step's work buffer is laid out per call (by the number of hypotheses) and shared with the essential-matrix
+    run; the one-launch stage of short runs (k_pose_small) counts finished blocks in a word of its own, which must read
+    zero whatever ran in between (a word inside the shared buffer did not: the last block never scanned and the run
+    returned the record of an earlier one)."""
+    rng = np.random.default_rng(5)
+    xy, X, *_ = synth.pnp_scene(300, seed=91, outlier_frac=0.2)
+    want = oracle.p3p_ransac(xy, X, K, num_hyp=2000, max_reproj=2.0, confidence=0.99, seed=3, mode=1, min_inliers=4, threads=8)
+    p0 = rng.uniform(50, 1100, (400, 2)); p1 = p0 + rng.normal(0, 2, p0.shape)
+    for other in range(4):
+        if other == 1:
+            ops.essential_ransac(p0, p1, K, num_hyp=700, confidence=0.0, seed=1, ctx=ctx)
+        elif other == 2:
+            big, bigX, *_ = synth.pnp_scene(5000, seed=92, outlier_frac=0.3)
+            ops.p3p_ransac(big, bigX, K, num_hyp=3000, max_reproj_err=2.0, confidence=0.0, seed=4, mode=1, ctx=ctx)
+        elif other == 3:
+            ops.p3p_ransac(xy, X, K, num_hyp=600, max_reproj_err=2.0, confidence=0.99, seed=9, mode=0, ctx=ctx)
+        got = ops.p3p_ransac(xy, X, K, num_hyp=2000, max_reproj_err=2.0, confidence=0.99, seed=3, mode=1, min_inliers=4, ctx=ctx)
+        assert (got["status"], got["trials"], got["best_hyp"], got["best_sol"]) == (want["status"], want["trials"], want["best_hyp"], want["best_sol"]), other
+        np.testing.assert_array_equal(got["inliers"], want["inliers"])
+
+
 def test_ransac_adaptive_run_still_scores_everything_when_asked(ctx):
     """Per-hypothesis outputs (counts, costs, poses) of an adaptive run cover all hypotheses, not just the first stage."""
     xy, X, *_ = synth.pnp_scene(1200, seed=78, outlier_frac=0.2)

@@ -68,8 +68,8 @@ int vo_ctx_create(int device, vo_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long) + 256) != hipSuccess   /* + vo_stats_gather's staging */ ||
-        hipMemset(c->d_counters, 0, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void**)&c->d_counters, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long) + 512) != hipSuccess   /* + vo_stats_gather's staging (256 B) + the pose step's ticket (256 B) */ ||
+        hipMemset(c->d_counters, 0, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long) + 512) != hipSuccess) {
         vo_ctx_destroy(c);
         return VO_ERR_HIP;
     }
