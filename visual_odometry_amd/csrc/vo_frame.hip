@@ -222,11 +222,16 @@ constexpr int MERGE_ONE_BLOCK = 1280; // landmarks + candidates up to which the 
 // owns elements and walks the pool in LDS (broadcast reads).  The equivalence with the sequential policy is
 // checked on tie-heavy random pools (tests/test_host_logic.py) and per frame against the oracle's sequential
 // restatement (tests/test_gpu_frame.py).
-__global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a) {
+// ... and, in the same launch, what k_compact2 does behind the three-launch form: block 1 keeps the aged candidates
+// (it needs the classes only, not the merge), block 0 goes on to the final landmark order once its merge is written
+// (one launch less in the chain every frame runs through).
+__global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a, CandOp cop, int nc, int32_t* count_c, LandmarkOp lop, int32_t* count_l,
+                                                    int32_t* sizes) {
     __shared__ double s_v[MERGE_LDS];
     __shared__ int32_t s_pidx[MERGE_LDS];
     __shared__ uint8_t s_acc[MERGE_LDS], s_surv[MERGE_LDS];
     __shared__ int s_w[16];
+    if (blockIdx.x == 1) { compact_block(cop, nc, count_c, sizes + 1, s_w); return; }
     const int tid = threadIdx.x;
     const int n0 = *a.n0, nC = *a.nC_dev;
     // ordered list of the promotable candidates
@@ -294,6 +299,10 @@ __global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a) {
     }
     for (int i = tid; i < n0; i += 1024) a.alive[i] = s_surv[i];
     if (tid == 0) *a.n_promoted = prom;
+    __syncthreads();                       // the block's own stores (alive, the appended entries) are visible to all of it
+    compact_block(lop, a.PW, count_l, nullptr, s_w);
+    __syncthreads();
+    if (tid == 0) sizes[0] = *count_l < a.cap ? *count_l : a.cap;
 }
 
 // The same in three launches for pools beyond a few hundred entries, where one block walking all pairs is too
@@ -866,20 +875,21 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         m.n_promoted = counts + 8; m.c = ca;
         // small pools: one block does it all.  Either form is right for any pool that fits the work arrays; which
         // one is faster is guessed from the last collected frame's counts (the pool grows by at most `keep` a frame)
+        // the aged candidates and the final landmark order are independent: a block each -- of the one-block merge's
+        // launch, or of a launch of their own behind the wide form; the landmarks' block also leaves the number of
+        // landmarks the next frame starts from (st->sizes[0])
+        CandOp cop = {ca, cc, st->cq, st->cf[s], st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]};
+        LandmarkOp lop = {st->alive, pw, cl, st->wkp, st->wL, st->wrep, st->kp[n], st->L[n], st->rep[n]};
         if (pw <= MERGE_LDS && nL_hint + nC_hint + VO_FRAME_MAX_PENDING * o.sel.keep <= MERGE_ONE_BLOCK) {
-            hipLaunchKernelGGL(k_merge_par, dim3(1), dim3(1024), 0, sm, m);
+            hipLaunchKernelGGL(k_merge_par, dim3(2), dim3(1024), 0, sm, m, cop, cc, counts + 1, lop, counts + 0, st->sizes);
         } else {                                               // the all-pairs counts spread over the chip
             MergeWideArgs mw = {m, st->pin, (uint8_t*)st->pos, (uint8_t*)st->pos + pw, counts + 9};
             hipLaunchKernelGGL(k_merge_list, dim3(1), dim3(1024), 0, sm, mw);
             hipLaunchKernelGGL(k_merge_rank, dim3(blocks(16 * pw)), dim3(256), 0, sm, mw);
             hipLaunchKernelGGL(k_merge_write, dim3(1), dim3(1024), 0, sm, mw);
+            hipLaunchKernelGGL((k_compact2<CandOp, LandmarkOp>), dim3(2), dim3(1024), 0, sm, cop, cc, counts + 1, st->sizes + 1, lop, pw, counts + 0,
+                               st->sizes + 0, cl);
         }
-        // the aged candidates and the final landmark order are independent: one launch, a block each; the landmarks'
-        // block also leaves the number of landmarks the next frame starts from (st->sizes[0])
-        CandOp cop = {ca, cc, st->cq, st->cf[s], st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]};
-        LandmarkOp lop = {st->alive, pw, cl, st->wkp, st->wL, st->wrep, st->kp[n], st->L[n], st->rep[n]};
-        hipLaunchKernelGGL((k_compact2<CandOp, LandmarkOp>), dim3(2), dim3(1024), 0, sm, cop, cc, counts + 1, st->sizes + 1, lop, pw, counts + 0,
-                           st->sizes + 0, cl);
     }
     stamp(sm, 8);
     // The next frame's landmark branch may start here -- one launch later when there is a selection: its k_uniform is
