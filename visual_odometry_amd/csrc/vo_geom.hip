@@ -93,6 +93,86 @@ __device__ void svd4_last(double* A, double* vout) {
     }
 }
 
+// The same iteration on TWO lanes per matrix (k_triangulate): a thread alone on its SIMD issues one instruction every
+// ~8 cycles whatever the dependencies, so the kernel's time is a thread's instruction count, and the two rotations of a
+// round are independent.  Lane 0 of a pair keeps column 0 and its partner of the round, lane 1 the other two; between
+// rounds one column (of A and of V) changes hands through a DPP quad permute.  Every rotation is computed by the
+// expressions above on the values the serial form would hold: same bits.
+struct JCol { double a[4], v[4]; };
+__device__ __forceinline__ double pair_xchg(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: the other lane of the pair
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ JCol pair_xchg(const JCol& c) {
+    JCol o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o.a[k] = pair_xchg(c.a[k]); o.v[k] = pair_xchg(c.v[k]); }
+    return o;
+}
+__device__ __forceinline__ bool jacobi_pair_rotate(JCol& P, JCol& Q) {
+    double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        alpha += P.a[k] * P.a[k];
+        beta += Q.a[k] * Q.a[k];
+        gamma += P.a[k] * Q.a[k];
+    }
+    const double zeta = (beta - alpha) / (2.0 * gamma);
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    double c = 1.0 / sqrt(1.0 + t * t);
+    double sn = c * t;
+    if (gamma == 0.0) { c = 1.0; sn = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double ap = P.a[k], aq = Q.a[k];
+        P.a[k] = c * ap - sn * aq; Q.a[k] = sn * ap + c * aq;
+        const double vp = P.v[k], vq = Q.v[k];
+        P.v[k] = c * vp - sn * vq; Q.v[k] = sn * vp + c * vq;
+    }
+    return c != 1.0;
+}
+// A: the full 4x4 matrix (both lanes hold it), role: 0 / 1 = the lane of the pair; vout on both lanes
+__device__ __forceinline__ void svd4_last_pair(const double* A, int role, double* vout) {
+    JCol P, Q;   // lane 0: columns (0,1); lane 1: (2,3)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        P.a[k] = role ? A[k * 4 + 2] : A[k * 4 + 0];
+        Q.a[k] = role ? A[k * 4 + 3] : A[k * 4 + 1];
+        P.v[k] = (k == (role ? 2 : 0)) ? 1.0 : 0.0;
+        Q.v[k] = (k == (role ? 3 : 1)) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        bool rot = jacobi_pair_rotate(P, Q);                        // (0,1) (2,3)
+        JCol got = pair_xchg(role ? P : Q);                         // lane 0 gives column 1, lane 1 column 2
+        if (role) P = got; else Q = got;                            // (0,2) (1,3)
+        rot |= jacobi_pair_rotate(P, Q);
+        got = pair_xchg(Q);                                         // columns 2 and 3 change sides
+        Q = got;                                                    // (0,3) (1,2)
+        rot |= jacobi_pair_rotate(P, Q);
+        got = pair_xchg(role ? P : Q);                              // lane 0 gives column 3, lane 1 column 1
+        if (role) { P = Q; Q = got; } else Q = got;                 // (0,1) (2,3) again
+        const int other = __builtin_amdgcn_mov_dpp((int)rot, 0xB1, 0xF, 0xF, true);
+        if (!(rot || other)) break;
+    }
+    double nP = 0, nQ = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { nP += P.a[k] * P.a[k]; nQ += Q.a[k] * Q.a[k]; }
+    const double oP = pair_xchg(nP), oQ = pair_xchg(nQ);
+    const double nn[4] = {role ? oP : nP, role ? oQ : nQ, role ? nP : oP, role ? nQ : oQ};
+    int best = 0; double bn = INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (nn[j] < bn) { bn = nn[j]; best = j; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double mine = (best & 1) ? Q.v[k] : P.v[k];
+        const double theirs = pair_xchg(mine);
+        vout[k] = (best >> 1) == role ? mine : theirs;
+    }
+}
+
 struct TriArgs {
     const double *xy0, *xy1; vo_strides sxy;
     const double* poses0; int pose_col_major; const int32_t* pose_idx; int C, P;
@@ -113,12 +193,15 @@ __global__ __launch_bounds__(256) void k_triangulate(TriArgs a) {
         for (int k = 0; k < 9; ++k) s_K[k] = K[k];
     }
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 128 + (threadIdx.x >> 1);   // two lanes per candidate (svd4_last_pair)
+    const int role = threadIdx.x & 1;
     if (i >= (a.C_dev ? min(a.C, *a.C_dev) : a.C)) return;
     int pi = a.pose_idx ? a.pose_idx[i] : i;
     if (pi < 0 || pi >= a.P) { // invalid table index: flag the candidate instead of reading out of bounds
-        a.valid[i] = 0; a.reproj[i] = __builtin_nan(""); a.angle[i] = __builtin_nan("");
-        for (int c = 0; c < 3; ++c) a.X[i * a.sX.xi + c * a.sX.xc] = __builtin_nan("");
+        if (role == 0) {
+            a.valid[i] = 0; a.reproj[i] = __builtin_nan(""); a.angle[i] = __builtin_nan("");
+            for (int c = 0; c < 3; ++c) a.X[i * a.sX.xi + c * a.sX.xc] = __builtin_nan("");
+        }
         return;
     }
     double pose0[12], K[9], cam0[12], cam1[12];
@@ -136,7 +219,8 @@ __global__ __launch_bounds__(256) void k_triangulate(TriArgs a) {
         A[2 * 4 + k] = x1 * cam1[k * 3 + 2] - cam1[k * 3 + 0];
         A[3 * 4 + k] = y1 * cam1[k * 3 + 2] - cam1[k * 3 + 1];
     }
-    svd4_last(A, h);
+    svd4_last_pair(A, role, h);
+    if (role) return;
     double Xi[3] = {h[0] / h[3], h[1] / h[3], h[2] / h[3]};
     double u, v, w0, w1;
     project(cam0, Xi, u, v, w0);
@@ -198,7 +282,7 @@ int vo_launch_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1,
     a.xy0 = d_xy0; a.xy1 = d_xy1; a.sxy = sxy; a.poses0 = d_poses0; a.pose_col_major = pose_col_major;
     a.pose_idx = d_pose_idx; a.C = C; a.P = P; a.pose1 = d_pose1; a.K = d_K; a.X = d_X; a.sX = sX;
     a.reproj = d_reproj; a.angle = d_angle; a.valid = d_valid; a.C_dev = d_C;
-    hipLaunchKernelGGL(k_triangulate, dim3((C + 255) / 256), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_triangulate, dim3((C + 127) / 128), dim3(256), 0, ctx->stream, a);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }
