@@ -116,16 +116,18 @@ __device__ __forceinline__ void cp3(double* d, const double* s) { d[0] = s[0]; d
 
 // old/p3p.m:41-217.  Pw: 3 world points (row i = point i); fv: 3 unit bearings.  poses: 4 x 12
 // [C(3) R(9 row-major, cam->world)]
-__device__ void p3p_device(const double* Pw, const double* fv, double* poses) {
-    for (int k = 0; k < 48; ++k) poses[k] = 0.0;
-    double P1[3], P2[3], P3[3], f1[3], f2[3], f3[3];
+struct P3PFront { double P1[3], N[9], T[9], f_1, f_2, p_1, p_2, d_12, b; double xr[4]; bool ok; };
+// everything up to the quartic's roots (shared by the four solutions) ...
+__device__ __forceinline__ void p3p_front(const double* Pw, const double* fv, P3PFront& F) {
+    F.ok = false;
+    double* const P1 = F.P1; double P2[3], P3[3], f1[3], f2[3], f3[3];
     cp3(P1, Pw); cp3(P2, Pw + 3); cp3(P3, Pw + 6);
     double v1[3], v2[3], cr[3];
     for (int i = 0; i < 3; ++i) { v1[i] = P2[i] - P1[i]; v2[i] = P3[i] - P1[i]; }
     cross3(v1, v2, cr);
-    if (sqrt(dot3(cr, cr)) == 0.0) return;
+    if (sqrt(dot3(cr, cr)) == 0.0) return;   // collinear points: no solutions (F.ok stays false)
     cp3(f1, fv); cp3(f2, fv + 3); cp3(f3, fv + 6);
-    double T[9], e3n;
+    double* const T = F.T; double e3n;
     {
         double* e1 = T; double* e2 = T + 3; double* e3 = T + 6;
         cp3(e1, f1);
@@ -147,7 +149,7 @@ __device__ void p3p_device(const double* Pw, const double* fv, double* poses) {
         matvec3(T, f3, f3t);
         cp3(P1, Pw + 3); cp3(P2, Pw); cp3(P3, Pw + 6);
     }
-    double N[9];
+    double* const N = F.N;
     {
         double* n1 = N; double* n2 = N + 3; double* n3 = N + 6;
         double d[3], nn;
@@ -189,9 +191,15 @@ __device__ void p3p_device(const double* Pw, const double* fv, double* poses) {
              p_2_pw2 * f_1_pw2 * p_1_pw2 + f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
     cpx x[4];
     solve_quartic(fac, x);
-
-    for (int i = 0; i < 4; ++i) {
-        const double xr = x[i].re;
+    for (int i = 0; i < 4; ++i) F.xr[i] = x[i].re;
+    F.f_1 = f_1; F.f_2 = f_2; F.p_1 = p_1; F.p_2 = p_2; F.d_12 = d_12; F.b = b;
+    F.ok = true;
+}
+// ... and the back-substitution of one root: pose12 = [C(3) R(9 row-major, cam->world)] (old/p3p.m:187-215)
+__device__ __forceinline__ void p3p_root(const P3PFront& F, double xr, double* pose12) {
+    const double f_1 = F.f_1, f_2 = F.f_2, p_1 = F.p_1, p_2 = F.p_2, d_12 = F.d_12, b = F.b;
+    const double* const N = F.N; const double* const T = F.T; const double* const P1 = F.P1;
+    {
         const double cot_alpha = (-f_1 * p_1 / f_2 - xr * p_2 + d_12 * b) / (-f_1 * xr * p_2 / f_2 + p_1 - d_12);
         const double cos_theta = xr;
         const double st2 = 1 - xr * xr;
@@ -214,9 +222,16 @@ __device__ void p3p_device(const double* Pw, const double* fv, double* poses) {
         for (int r = 0; r < 3; ++r)
             for (int c = 0; c < 3; ++c)
                 Rw[r * 3 + c] = (NR[r * 3 + 0] * T[0 * 3 + c] + NR[r * 3 + 1] * T[1 * 3 + c]) + NR[r * 3 + 2] * T[2 * 3 + c];
-        cp3(poses + 12 * i, Cw);
-        for (int k2 = 0; k2 < 9; ++k2) poses[12 * i + 3 + k2] = Rw[k2];
+        cp3(pose12, Cw);
+        for (int k2 = 0; k2 < 9; ++k2) pose12[3 + k2] = Rw[k2];
     }
+}
+__device__ void p3p_device(const double* Pw, const double* fv, double* poses) {
+    for (int k = 0; k < 48; ++k) poses[k] = 0.0;
+    P3PFront F;
+    p3p_front(Pw, fv, F);
+    if (!F.ok) return;
+    for (int i = 0; i < 4; ++i) p3p_root(F, F.xr[i], poses + 12 * i);
 }
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], const uint32_t key[2]) {
@@ -300,6 +315,40 @@ __device__ __forceinline__ void hyp_body(const HypArgs& a, int M, int h, double*
             for (int k = 0; k < 3; ++k) lds[12 * s + 9 + k] = t[k];
         }
     }
+}
+
+// the same on FOUR lanes, one per solution (k_pose_small): sampling and everything up to the quartic's roots are
+// computed by all four, the back-substitution and the change to [R_cw | t_cw] -- more than half of a thread's
+// instructions -- by the lane of the root.  A wave alone on its SIMD is bound by its instruction count.
+__device__ __forceinline__ void hyp_body4(const HypArgs& a, int M, int h, int r, double* lds) {
+    double K[9];
+    for (int k = 0; k < 9; ++k) K[k] = a.K[k];
+    int32_t id[3];
+    bool ok = true;
+    if (a.sample_idx) {
+        for (int k = 0; k < 3; ++k) { id[k] = a.sample_idx[3 * h + k]; if (id[k] < 0 || id[k] >= M) ok = false; }
+    } else philox_sample3(a.seed, (uint32_t)h, (uint32_t)M, id);
+    double pose[12];
+    for (int k = 0; k < 12; ++k) pose[k] = 0.0;   // a null hypothesis (table entry out of range, collinear points)
+    if (ok) {
+        double Pw[9], f[9];
+        for (int k = 0; k < 3; ++k) {
+            const long i = id[k];
+            for (int c = 0; c < 3; ++c) Pw[3 * k + c] = a.X[i * a.sX.xi + c * a.sX.xc];
+            bearing(K, a.xy[i * a.sxy.xi], a.xy[i * a.sxy.xi + a.sxy.xc], f + 3 * k);
+        }
+        P3PFront F;
+        p3p_front(Pw, f, F);
+        if (F.ok) p3p_root(F, r == 0 ? F.xr[0] : (r == 1 ? F.xr[1] : (r == 2 ? F.xr[2] : F.xr[3])), pose);
+    }
+    const double* C = pose; const double* Rwc = pose + 3;
+    double R[9], t[3];
+    for (int i = 0; i < 3; ++i)
+        for (int c = 0; c < 3; ++c) R[i * 3 + c] = Rwc[c * 3 + i];
+    for (int i = 0; i < 3; ++i) t[i] = -((R[i * 3] * C[0] + R[i * 3 + 1] * C[1]) + R[i * 3 + 2] * C[2]);
+    double* o = a.Rt + 48 * (long)h + 12 * r;
+    for (int k = 0; k < 9; ++k) { o[k] = R[k]; lds[12 * r + k] = R[k]; }
+    for (int k = 0; k < 3; ++k) { o[9 + k] = t[k]; lds[12 * r + 9 + k] = t[k]; }
 }
 
 __global__ __launch_bounds__(64, 4) void k_hyp(HypArgs a) {   // <= 128 VGPRs: fits the hole one finished tracking wave leaves (160 did not: the kernel starved beside k_lk)
@@ -645,8 +694,8 @@ __global__ __launch_bounds__(BEST_NT) void k_best(BestArgs a) {
 
 // ---- short point sets (the frame loop: 300 landmarks): a stage of the adaptive run in ONE launch ----
 // k_hyp -> k_score -> k_best are three launches of a few microseconds of work each when the points are few, and two
-// stages make six.  Here a one-wave block generates its two hypotheses (two lanes; the P3P solve is one thread's
-// chain either way), scores their eight poses on ALL points (so its sums are stores, nothing has to be zeroed), and
+// stages make six.  Here a one-wave block generates its two hypotheses (four lanes each, one per solution of the
+// P3P solve), scores their eight poses on ALL points (so its sums are stores, nothing has to be zeroed), and
 // the block that finishes last -- a ticket counted up behind a fence -- runs k_best's scan.  Same device functions,
 // same bits (test_ransac_adaptive_run_in_two_stages runs both forms against the oracle).
 struct SmallArgs { HypArgs h; ScoreArgs s; BestArgs b; int32_t* ticket; int nblocks; };
@@ -661,9 +710,9 @@ __global__ __launch_bounds__(64, 4) void k_pose_small(SmallArgs a) {
     if (a.h.M_dev) M = min(M, *a.h.M_dev);
     if (M < 4) { if (blockIdx.x == 0) best_body<64>(a.b); return; }   // status 1 and the identity (uniform per block)
     const int tid = threadIdx.x;
-    if (tid < SC_HB) {
-        const int h = a.h.h0 + (int)blockIdx.x * SC_HB + tid;
-        if (h < a.h.H) hyp_body(a.h, M, h, s_pose + 48 * tid);
+    if (tid < 4 * SC_HB) {                                // four lanes per hypothesis, one per solution
+        const int h = a.h.h0 + (int)blockIdx.x * SC_HB + (tid >> 2);
+        if (h < a.h.H) hyp_body4(a.h, M, h, tid & 3, s_pose + 48 * (tid >> 2));
     }
     __syncthreads();
     score_body(a.s, s_pose);
