@@ -129,6 +129,8 @@ int vo_launch_angle(vo_ctx* ctx, const double* d_X, vo_strides sX, int n, const 
                     const double* d_pose1, int pose_col_major, double* d_angle);
 int vo_launch_in_front(vo_ctx* ctx, const double* d_cam, int cam_col_major, const double* d_X, vo_strides sX,
                        int n, uint8_t* d_valid);
+// flags for events that only order streams of one device (not read by the host): VO_EVENT_FLAGS overrides (A/B)
+unsigned vo_int_event_flags();
 int vo_launch_reproj(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const double* d_X, vo_strides sX, int n,
                      const double* d_pose, int pose_col_major, const double* d_K, double* d_err,
                      const int32_t* d_n = nullptr);   // d_n: the count on the device (n is then its upper bound)

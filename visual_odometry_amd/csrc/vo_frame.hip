@@ -552,10 +552,10 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     if (e == hipSuccess) e = hipMalloc((void**)&st->img[0], (size_t)nu * nv);
     if (e == hipSuccess) e = hipMalloc((void**)&st->img[1], (size_t)nu * nv);
     if (e == hipSuccess) e = hipMalloc((void**)&st->img[2], (size_t)nu * nv);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_ready, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_fork_la, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_state, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_pose, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_ready, vo_int_event_flags());
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_fork_la, vo_int_event_flags());
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_state, vo_int_event_flags());
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_pose, vo_int_event_flags());
     st->overlap = !getenv("VO_FRAME_SERIAL");
     if (const char* sp = getenv("VO_FRAME_STAMPS")) {
         st->stamp_path = sp;
@@ -563,8 +563,8 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
         if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_stamps, (size_t)STAMP_FRAMES * STAMP_N * sizeof(long long), 0);
         if (e == hipSuccess) memset(st->h_stamps, 0, (size_t)STAMP_FRAMES * STAMP_N * sizeof(long long));
     }
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[0], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[1], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[0], vo_int_event_flags());
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[1], vo_int_event_flags());
     if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_counts, 16 * sizeof(int32_t), 0);
     if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_rec, VO_FRAME_MAX_PENDING * 40 * sizeof(double), 0);
     for (int k = 0; k < VO_FRAME_MAX_PENDING && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&st->ev_rec[k], hipEventDisableTiming);
