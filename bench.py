@@ -296,7 +296,8 @@ def main():
     ctx = _lib.Context(local_rank)
     nl = args.keypoints // 2
     nc = args.keypoints - nl
-    wl = FrameWorkload(ctx, nl, nc, num_hyp=args.hyp, seed=1023 + 7919 * rank)
+    # one ctx per process and one process per GPU: the lane may be a high-priority stream (not in the one-GPU rehearsal)
+    wl = FrameWorkload(ctx, nl, nc, num_hyp=args.hyp, seed=1023 + 7919 * rank, lane_priority=not os.environ.get("VO_REHEARSE_ONE_GPU"))
 
     # Device spin-up, untimed and before the W warm-up steps: the first few hundred milliseconds after an idle
     # period run ~3 % slower than the steady state (clocks / power state: 1.26-1.27 ms per step right after the

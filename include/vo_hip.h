@@ -103,7 +103,7 @@ void vo_ctx_destroy(vo_ctx* ctx);
 int vo_ctx_set_stream(vo_ctx* ctx, void* hip_stream);
 void* vo_ctx_get_stream(vo_ctx* ctx);
 int vo_ctx_sync(vo_ctx* ctx);
-/* A branch of a frame's dependency graph on a second, high-priority stream (the reference has no counterpart: MATLAB
+/* A branch of a frame's dependency graph on a second stream (high-priority on request: vo_ctx_lane_priority) (the reference has no counterpart: MATLAB
  * runs the steps of modules/VisualOdometry.m:264-346 one after the other, although the pose step :285-289 needs only
  * the landmark tracks of :278 and the candidate tracking of :71 needs neither).  Between _begin and _end every
  * vo_dev_* call of this ctx is enqueued on the lane stream, which starts behind everything enqueued on the ctx stream
@@ -117,6 +117,12 @@ int vo_ctx_lane_begin(vo_ctx* ctx);
 int vo_ctx_lane_resume(vo_ctx* ctx);
 int vo_ctx_lane_end(vo_ctx* ctx);
 int vo_ctx_lane_join(vo_ctx* ctx);
+/* No counterpart in the reference.  high != 0: the lane is created as a high-priority stream, so that its tracking
+ * launch is dispatched in front of the ctx stream's (the landmark track ends first and the pose chain runs beside the
+ * rest of the candidate track: 0.1 ms of a 50k-keypoint step).  Only for a process that holds ONE ctx on a GPU it does
+ * not share: with more hardware queues than the process may hold, a high-priority stream can wait for ever.  Before
+ * the lane's first use; the default is the ctx stream's priority. */
+int vo_ctx_lane_priority(vo_ctx* ctx, int high);
 const char* vo_ctx_last_error(vo_ctx* ctx);
 /* counters: [0] LK iterations executed (window passes), [1] keypoints tracked, [2] LK template
  * set-ups (level x direction x point), [3] hypotheses scored */

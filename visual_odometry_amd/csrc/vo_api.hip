@@ -154,8 +154,13 @@ int vo_int_lane_ensure(vo_ctx* ctx) {
     if (!ctx->lane) {
         int lo = 0, hi = 0;   // numerically lower = higher priority
         VO_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        // VO_LANE_NORMAL_PRIORITY=1: the lane at the ctx stream's priority (A/B switch; see DESIGN "Schedule of a step")
-        if (getenv("VO_LANE_NORMAL_PRIORITY")) VO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->lane, hipStreamNonBlocking));
+        // The lane has the ctx stream's priority unless the caller asked for more (vo_ctx_lane_priority) -- a caller who
+        // is alone on the GPU with ONE ctx.  A high-priority stream beside more hardware queues than the process may
+        // hold (GPU_MAX_HW_QUEUES = 4: a second ctx's streams, even destroyed ones; another process on the GPU) waits
+        // for events of streams that no longer get to run: the frame loop stood still in exactly that order of tests.
+        // VO_LANE_NORMAL_PRIORITY=1 overrules the request (A/B switch; DESIGN "Schedule of a step").
+        if (!ctx->lane_high_priority || getenv("VO_LANE_NORMAL_PRIORITY"))
+            VO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->lane, hipStreamNonBlocking));
         else VO_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->lane, hipStreamNonBlocking, hi));
         VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_fork, vo_int_event_flags()));
         VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_done, vo_int_event_flags()));
@@ -175,6 +180,12 @@ int vo_ctx_lane_begin(vo_ctx* ctx) {
     ctx->lane_saved = ctx->stream;
     ctx->stream = ctx->lane;
     ctx->in_lane = true;
+    return VO_OK;
+}
+int vo_ctx_lane_priority(vo_ctx* ctx, int high) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    if (ctx->lane) { ctx->last_error = "vo_ctx_lane_priority: the lane exists already (call this before its first use)"; return VO_ERR_BAD_ARG; }
+    ctx->lane_high_priority = high != 0;
     return VO_OK;
 }
 int vo_ctx_lane_resume(vo_ctx* ctx) {

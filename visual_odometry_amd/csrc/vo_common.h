@@ -54,6 +54,7 @@ struct vo_ctx {
     hipStream_t lane = nullptr, lane_saved = nullptr;
     hipEvent_t ev_lane_fork = nullptr, ev_lane_done = nullptr;
     bool in_lane = false, lane_pending = false;
+    bool lane_high_priority = false;   // vo_ctx_lane_priority: asked for before the lane exists
     struct vo_sel_pending* sel_pending = nullptr;  // vo_dev_select_begin .. vo_dev_select_finish
     uint64_t sel_gen[2] = {0, 0};   // bumped whenever a selection work area is handed out: work issued ahead into it
                                     // (look-ahead, open selections) is valid only while the number stands

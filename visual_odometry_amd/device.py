@@ -22,7 +22,8 @@ def _p(t):
 
 class FrameWorkload:
     def __init__(self, ctx, n_landmarks, n_candidates, nv=376, nu=1241, n_frames=16, num_hyp=2000, levels=4,
-                 block=41, max_iters=50, eps=0.01, max_bidir=2.0, keep=100, seed=1023, device=None, ahead=None):
+                 block=41, max_iters=50, eps=0.01, max_bidir=2.0, keep=100, seed=1023, device=None, ahead=None,
+                 lane_priority=False):
         """ahead: the image-only work of a frame (pyramid, corner detection) is issued one step ahead on the side
         stream (vo_dev_frame_prefetch); None: on unless VO_NO_PREFETCH is set (A/B switch for profiling)."""
         self.ctx = ctx
@@ -31,6 +32,13 @@ class FrameWorkload:
         # (modules/VisualOdometry.m: the pose step :285-289 needs the landmark tracks of :278 only, the candidate
         # tracking of :71 neither).  VO_NO_LANE=1: one tracking launch over both sets, then the pose (A/B switch).
         self.lane = not os.environ.get("VO_NO_LANE")
+        # lane_priority: the lane as a high-priority stream (vo_ctx_lane_priority) -- for a process with one ctx on a GPU of
+        # its own (bench.py); refused, and ignored here, once the ctx's lane exists
+        if lane_priority and self.lane:
+            try:
+                ctx.call("vo_ctx_lane_priority", 1)
+            except Exception:
+                pass
         self.dev = torch.device("cuda", ctx.device if device is None else device)
         self.nu, self.nv, self.levels, self.block = nu, nv, levels, block
         self.max_iters, self.eps, self.max_bidir = max_iters, eps, max_bidir
