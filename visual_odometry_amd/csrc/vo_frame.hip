@@ -36,8 +36,8 @@ __device__ __forceinline__ int block_excl_scan_1024(int flag, int* total, int* s
     return base + within;
 }
 
-// ordered compaction in one launch: Op::flag(i) says whether element i stays, Op::move(i, d) puts it at
-// position d of the output; *count = number kept.  One block walks the n elements 1024 at a time.
+// ordered compaction by one block: Op::flag(i) says whether element i stays, Op::move(i, d) puts it at
+// position d of the output; *count = number kept.  The block walks the n elements 1024 at a time.
 template <class Op>
 __device__ __forceinline__ void compact_block(const Op& op, int n, int32_t* count, const int32_t* n_dev, int* s_w) {
     if (n_dev) n = min(n, *n_dev);   // the count lives on the device, n is its upper bound
@@ -51,11 +51,6 @@ __device__ __forceinline__ void compact_block(const Op& op, int n, int32_t* coun
         base += tot;
     }
     if (threadIdx.x == 0 && count) *count = base;
-}
-template <class Op>
-__global__ __launch_bounds__(1024) void k_compact(Op op, int n, int32_t* count, const int32_t* n_dev = nullptr) {
-    __shared__ int s_w[16];
-    compact_block(op, n, count, n_dev, s_w);
 }
 // two independent compactions in one launch: block 0 does A, block 1 does B
 template <class OpA, class OpB>

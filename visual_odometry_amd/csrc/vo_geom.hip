@@ -26,78 +26,13 @@ __device__ __forceinline__ double angle_deg(const double* X, const double* c0, c
 
 // One-sided Jacobi as oracle/geom.c svd4_last defines it: a sweep is three rounds of two disjoint column pairs,
 // (0,1)(2,3) / (0,2)(1,3) / (0,3)(1,2); it ends with the first sweep all of whose rotations were the identity up
-// to rounding (c == 1.0), after 12 sweeps at the latest.  A thread's time here is one long chain of dependent
-// fp64 divisions and square roots: the two rotations of a round are written side by side so that their chains
-// interleave, and the early end halves the sweeps (5-6 instead of 12 on triangulation matrices).
-struct JRot { double c, s; };
-template <int P, int Q>
-__device__ __forceinline__ JRot jacobi_params(const double* A) {
-    double alpha = 0, beta = 0, gamma = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        alpha += A[k * 4 + P] * A[k * 4 + P];
-        beta += A[k * 4 + Q] * A[k * 4 + Q];
-        gamma += A[k * 4 + P] * A[k * 4 + Q];
-    }
-    const double zeta = (beta - alpha) / (2.0 * gamma);
-    const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-    JRot r;
-    r.c = 1.0 / sqrt(1.0 + t * t);
-    r.s = r.c * t;
-    if (gamma == 0.0) { r.c = 1.0; r.s = 0.0; }
-    return r;
-}
-template <int P, int Q>
-__device__ __forceinline__ void jacobi_apply(double* A, double* V, const JRot r) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double ap = A[k * 4 + P], aq = A[k * 4 + Q];
-        A[k * 4 + P] = r.c * ap - r.s * aq; A[k * 4 + Q] = r.s * ap + r.c * aq;
-        const double vp = V[k * 4 + P], vq = V[k * 4 + Q];
-        V[k * 4 + P] = r.c * vp - r.s * vq; V[k * 4 + Q] = r.s * vp + r.c * vq;
-    }
-}
-template <int P0, int Q0, int P1, int Q1>
-__device__ __forceinline__ bool jacobi_round(double* A, double* V) {
-    const JRot r0 = jacobi_params<P0, Q0>(A), r1 = jacobi_params<P1, Q1>(A);   // disjoint columns: independent
-    jacobi_apply<P0, Q0>(A, V, r0);
-    jacobi_apply<P1, Q1>(A, V, r1);
-    return (r0.c != 1.0) | (r1.c != 1.0);
-}
-
-__device__ void svd4_last(double* A, double* vout) {
-    double V[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) V[i] = (i % 5 == 0) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        bool rotated = jacobi_round<0, 1, 2, 3>(A, V);
-        rotated |= jacobi_round<0, 2, 1, 3>(A, V);
-        rotated |= jacobi_round<0, 3, 1, 2>(A, V);
-        if (!rotated) break;
-    }
-    int best = 0; double bn = INFINITY;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        double nn = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) nn += A[k * 4 + j] * A[k * 4 + j];
-        if (nn < bn) { bn = nn; best = j; }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        double v = V[k * 4 + 0];
-        if (best == 1) v = V[k * 4 + 1];
-        if (best == 2) v = V[k * 4 + 2];
-        if (best == 3) v = V[k * 4 + 3];
-        vout[k] = v;
-    }
-}
-
-// The same iteration on TWO lanes per matrix (k_triangulate): a thread alone on its SIMD issues one instruction every
-// ~8 cycles whatever the dependencies, so the kernel's time is a thread's instruction count, and the two rotations of a
-// round are independent.  Lane 0 of a pair keeps column 0 and its partner of the round, lane 1 the other two; between
-// rounds one column (of A and of V) changes hands through a DPP quad permute.  Every rotation is computed by the
-// expressions above on the values the serial form would hold: same bits.
+// to rounding (c == 1.0), after 12 sweeps at the latest (5-6 on triangulation matrices).  The right-singular vector
+// of the smallest column norm is the result.
+// On TWO lanes per matrix: a thread alone on its SIMD issues one instruction every ~8 cycles whatever the
+// dependencies, so the kernel's time is a thread's instruction count, and the two rotations of a round are
+// independent.  Lane 0 of a pair keeps column 0 and its partner of the round, lane 1 the other two; between rounds
+// one column (of A and of V) changes hands through a DPP quad permute.  Every rotation is the oracle's expression on
+// the values a one-thread form would hold: same bits (the one-thread form this replaced gave the same outputs).
 struct JCol { double a[4], v[4]; };
 __device__ __forceinline__ double pair_xchg(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
