@@ -209,16 +209,17 @@ def test_response_entry_points_leave_open_selections_alone(ctx):
         assert a[1] == b[1] and all(np.array_equal(x, y) for x, y in zip(a[2:], b[2:])) and np.array_equal(a[0], b[0])
 
 
-def test_lane_priority_is_asked_for_before_the_lane_exists():
-    """The lane has the ctx stream's priority unless vo_ctx_lane_priority asked for more before its first use (a
-    high-priority stream in a process with several contexts can wait for ever: the frame loop of this file's previous
-    test stood still behind test_steps_with_work_issued_ahead_equal_serial_steps while that was the default)."""
+def test_lane_priority_is_asked_for_before_the_lane_exists(ctx):
+    """The lane has the ctx stream's priority unless vo_ctx_lane_priority asked for more before its first use, and
+    the request is only granted to a ctx that is alone on its GPU in this process (tests/test_gpu_a_lane_guard.py
+    holds the grant, the refusal and the demotion): here the session's ctx exists, so asking is refused."""
     c = _lib.Context(0)
     try:
-        c.call("vo_ctx_lane_priority", 1)
-        c.call("vo_ctx_lane_priority", 0)                 # may change until the lane is created
-        c.call("vo_ctx_lane_begin"); c.call("vo_ctx_lane_end"); c.call("vo_ctx_lane_join"); c.sync()
-        with pytest.raises(Exception):
+        with pytest.raises(_lib.VoError, match="unsupported"):
             c.call("vo_ctx_lane_priority", 1)
+        c.call("vo_ctx_lane_priority", 0)                 # giving it up is always allowed until the lane is created
+        c.call("vo_ctx_lane_begin"); c.call("vo_ctx_lane_end"); c.call("vo_ctx_lane_join"); c.sync()
+        with pytest.raises(_lib.VoError, match="bad argument"):
+            c.call("vo_ctx_lane_priority", 0)
     finally:
         c.close()

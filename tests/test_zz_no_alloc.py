@@ -43,3 +43,36 @@ def test_static_entry_point_equals_the_allocating_one(ctx):
         _pose(ctx, torch, "vo_dev_p3p_ransac_static", small[0], small[1], RansacOpts(5121, 2.0, 0.0, 1, 1, 4))
     again = _pose(ctx, torch, "vo_dev_p3p_ransac_static", calls[1][0][0], calls[1][0][1], calls[1][1])
     assert again[0] == want[1][0] and np.array_equal(again[1], want[1][1])      # and still right after the refusal
+
+
+def test_static_entry_point_on_the_staged_path_and_without_any_allocation(ctx):
+    """From 4096 points and more than 512 hypotheses on, a run is staged (first hypotheses on every point, the others
+    sieved through two survivor lists: k_survivors, the bound and sieve words) -- all of it carved from the static
+    array, whose lists keep the previous call's entries.  Both modes, with and without the adaptive stop, twice, with a
+    smaller run in between; and the device's free memory does not move across the static calls (inputs and outputs
+    are allocated before the first of them)."""
+    import torch
+    big = synth.pnp_scene(5000, seed=61)
+    small = synth.pnp_scene(900, seed=62)
+    calls = [(big, RansacOpts(4000, 2.0, 0.0, 21, 1, 4)), (small, RansacOpts(700, 2.0, 0.0, 22, 1, 4)),
+             (big, RansacOpts(4000, 2.0, 0.0, 21, 1, 4)), (big, RansacOpts(4000, 2.0, 0.99, 23, 1, 4)),
+             (big, RansacOpts(4000, 2.0, 0.0, 24, 0, 30)), (small, RansacOpts(600, 2.0, 0.99, 25, 0, 30)),
+             (big, RansacOpts(4000, 2.0, 0.99, 26, 0, 30))]
+    want = [_pose(ctx, torch, "vo_dev_p3p_ransac", s[0], s[1], o) for s, o in calls]
+    d_K = torch.from_numpy(np.ascontiguousarray(K)).cuda()
+    bufs = []
+    for (xy, X, *_), o in calls:                   # everything a call touches exists before the first static call
+        bufs.append((torch.from_numpy(np.ascontiguousarray(xy)).cuda(), torch.from_numpy(np.ascontiguousarray(X)).cuda(),
+                     torch.full((16,), -7.0, dtype=torch.float64, device="cuda"),
+                     torch.full((len(xy),), 9, dtype=torch.uint8, device="cuda")))
+    torch.cuda.synchronize(); ctx.sync()
+    free0 = torch.cuda.mem_get_info()[0]
+    for (d_xy, d_X, out, inl), (s, o) in zip(bufs, calls):
+        ctx.call("vo_dev_p3p_ransac_static", ptr(d_xy), ptr(d_X), len(s[0]), ptr(d_K), C.byref(o), None, None, ptr(out), ptr(inl))
+    ctx.sync()
+    assert torch.cuda.mem_get_info()[0] == free0, "a static call changed the device's free memory"
+    for (d_xy, d_X, out, inl), (wb, wi) in zip(bufs, want):
+        assert out.cpu().numpy().tobytes() == wb and np.array_equal(inl.cpu().numpy(), wi)
+    assert want[0][0] == want[2][0]
+    info = np.frombuffer(want[0][0], np.int32, offset=96)
+    assert info[0] == 0 and want[0][1].sum() > 3000

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -42,11 +43,37 @@ const char* vo_strerror(int code) {
 }
 int vo_version(void) { return 100; }
 
+// all streams a ctx enqueues on have drained: the ctx stream (the lane itself while a lane is open), the stream the
+// lane was opened from, the side stream and the lane
+static hipError_t vo_int_quiesce(vo_ctx* ctx) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && ctx->in_lane) e = hipStreamSynchronize(ctx->lane_saved);
+    if (e == hipSuccess && ctx->side) e = hipStreamSynchronize(ctx->side);
+    if (e == hipSuccess && ctx->lane) e = hipStreamSynchronize(ctx->lane);
+    return e;
+}
+
+// ---- who holds streams of the library on a device (one process): see vo_ctx_lane_priority ----
+namespace {
+constexpr int VO_MAX_DEVICES = 64;
+struct DeviceRegistry { int ctx_ever = 0, pools_ever = 0; vo_ctx* hp_owner = nullptr; };
+std::mutex g_reg_mu;
+DeviceRegistry g_reg[VO_MAX_DEVICES];
+}
+void vo_int_register_streams(int device, vo_ctx* new_ctx_or_null) {
+    if (device < 0 || device >= VO_MAX_DEVICES) return;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    DeviceRegistry& r = g_reg[device];
+    if (new_ctx_or_null) ++r.ctx_ever; else ++r.pools_ever;
+    // whoever held a high-priority lane is no longer alone: it gives the priority up before the lane's next use
+    if (r.hp_owner && r.hp_owner != new_ctx_or_null) r.hp_owner->lane_demote.store(true, std::memory_order_release);
+    if (r.hp_owner && !new_ctx_or_null) r.hp_owner->lane_demote.store(true, std::memory_order_release);   // a pool of its own too
+}
+
 int vo_buf_reserve(vo_ctx* ctx, vo_buf* b, size_t bytes) {
     if (bytes <= b->cap) return VO_OK;
     if (b->p) {
-        VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->side) VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->side));   // work issued ahead may still read the old block
+        VO_HIP_CHECK(ctx, vo_int_quiesce(ctx));   // every stream of the ctx: work issued ahead or on the lane may still read the old block
         VO_HIP_CHECK(ctx, hipFree(b->p));
         b->p = nullptr; b->cap = 0;
     }
@@ -74,6 +101,7 @@ int vo_ctx_create(int device, vo_ctx** out) {
         return VO_ERR_HIP;
     }
     c->stream = c->own_stream;
+    vo_int_register_streams(device, c);
     if (vo_static_scratch_resolve(device) != VO_OK) {   // vo_dev_p3p_ransac_static's work array on this GPU
         vo_ctx_destroy(c);
         return VO_ERR_HIP;
@@ -84,6 +112,10 @@ int vo_ctx_create(int device, vo_ctx** out) {
 
 void vo_ctx_destroy(vo_ctx* c) {
     if (!c) return;
+    if (c->device >= 0 && c->device < VO_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        if (g_reg[c->device].hp_owner == c) g_reg[c->device].hp_owner = nullptr;
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
@@ -105,6 +137,7 @@ void vo_ctx_destroy(vo_ctx* c) {
         (void)hipStreamSynchronize(c->lane);
         (void)hipStreamDestroy(c->lane);
     }
+    if (c->ev_lane_guard) (void)hipEventDestroy(c->ev_lane_guard);
     if (c->ev_lane_fork) (void)hipEventDestroy(c->ev_lane_fork);
     if (c->ev_lane_done) (void)hipEventDestroy(c->ev_lane_done);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -151,20 +184,45 @@ unsigned vo_int_event_flags() {
 }
 
 int vo_int_lane_ensure(vo_ctx* ctx) {
+    const bool demote = ctx->lane_demote.load(std::memory_order_acquire) || getenv("VO_LANE_NORMAL_PRIORITY");
+    if (ctx->lane && ctx->lane_is_high && demote && !ctx->in_lane) {
+        // The ctx is no longer alone on its GPU (another ctx or a decode pool was created since the priority was
+        // granted): the high-priority stream is drained and replaced by one at the ctx stream's priority.  Events
+        // recorded on the old stream stay valid (all of them have completed by now).
+        VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lane));
+        VO_HIP_CHECK(ctx, hipStreamDestroy(ctx->lane));
+        ctx->lane = nullptr; ctx->lane_is_high = false; ctx->lane_high_priority = false;
+        VO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->lane, hipStreamNonBlocking));
+    }
     if (!ctx->lane) {
         int lo = 0, hi = 0;   // numerically lower = higher priority
         VO_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        // The lane has the ctx stream's priority unless the caller asked for more (vo_ctx_lane_priority) -- a caller who
-        // is alone on the GPU with ONE ctx.  A high-priority stream beside more hardware queues than the process may
-        // hold (GPU_MAX_HW_QUEUES = 4: a second ctx's streams, even destroyed ones; another process on the GPU) waits
-        // for events of streams that no longer get to run: the frame loop stood still in exactly that order of tests.
-        // VO_LANE_NORMAL_PRIORITY=1 overrules the request (A/B switch; DESIGN "Schedule of a step").
-        if (!ctx->lane_high_priority || getenv("VO_LANE_NORMAL_PRIORITY"))
+        // The lane has the ctx stream's priority unless the caller asked for more AND was granted it
+        // (vo_ctx_lane_priority: a ctx that is alone on its GPU).  A high-priority stream beside more hardware queues
+        // than the process may hold (GPU_MAX_HW_QUEUES = 4: a second ctx's streams, even destroyed ones; a decode
+        // pool's copy stream; another process on the GPU) waited for ever for an event of a stream that no longer got
+        // to run: the frame loop stood still in exactly that order of tests (DESIGN "Schedule of a step").
+        // VO_LANE_NORMAL_PRIORITY=1 overrules the request (A/B switch).
+        if (!ctx->lane_high_priority || demote) {
             VO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->lane, hipStreamNonBlocking));
-        else VO_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->lane, hipStreamNonBlocking, hi));
-        VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_fork, vo_int_event_flags()));
-        VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_done, vo_int_event_flags()));
+            ctx->lane_is_high = false;
+        } else {
+            VO_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->lane, hipStreamNonBlocking, hi));
+            ctx->lane_is_high = true;
+        }
+        if (!ctx->ev_lane_fork) VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_fork, vo_int_event_flags()));
+        if (!ctx->ev_lane_done) VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_done, vo_int_event_flags()));
     }
+    return VO_OK;
+}
+// An entry point called OUTSIDE the lane that uses a buffer the lane's work may still be using (the pose step's work
+// arrays: the frame loop's pose chain runs on the lane, asynchronously) first makes the ctx stream wait for whatever
+// the lane has been given so far.  Inside the lane, or without one, nothing is enqueued.
+int vo_int_wait_for_lane(vo_ctx* ctx) {
+    if (!ctx->lane || ctx->in_lane) return VO_OK;
+    if (!ctx->ev_lane_guard) VO_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_lane_guard, vo_int_event_flags()));
+    VO_HIP_CHECK(ctx, hipEventRecord(ctx->ev_lane_guard, ctx->lane));
+    VO_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_guard, 0));
     return VO_OK;
 }
 int vo_ctx_lane_begin(vo_ctx* ctx) {
@@ -185,12 +243,31 @@ int vo_ctx_lane_begin(vo_ctx* ctx) {
 int vo_ctx_lane_priority(vo_ctx* ctx, int high) {
     if (!ctx) return VO_ERR_BAD_ARG;
     if (ctx->lane) { ctx->last_error = "vo_ctx_lane_priority: the lane exists already (call this before its first use)"; return VO_ERR_BAD_ARG; }
-    ctx->lane_high_priority = high != 0;
+    if (ctx->device < 0 || ctx->device >= VO_MAX_DEVICES) return VO_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    DeviceRegistry& r = g_reg[ctx->device];
+    if (!high) {
+        ctx->lane_high_priority = false;
+        if (r.hp_owner == ctx) r.hp_owner = nullptr;
+        return VO_OK;
+    }
+    // granted only to a ctx that is, and always was, alone on its device in this process: every vo_ctx ever created
+    // there (destroyed ones too: their hardware queues were part of the order that hung) and every decode pool counts
+    if (r.ctx_ever > 1 || r.pools_ever > 0) {
+        ctx->last_error = "vo_ctx_lane_priority: refused -- this process has held another vo_ctx or a decode pool on this GPU "
+                          "(a high-priority lane beside more hardware queues than the process may hold can wait for ever); "
+                          "the lane keeps the ctx stream's priority";
+        return VO_ERR_UNSUPPORTED;
+    }
+    ctx->lane_high_priority = true;
+    ctx->lane_demote.store(false, std::memory_order_release);
+    r.hp_owner = ctx;
     return VO_OK;
 }
 int vo_ctx_lane_resume(vo_ctx* ctx) {
     if (!ctx) return VO_ERR_BAD_ARG;
     if (ctx->in_lane || !ctx->lane) { ctx->last_error = "vo_ctx_lane_resume: no lane to resume (or one is open)"; return VO_ERR_BAD_ARG; }
+    { int rc = vo_int_lane_ensure(ctx); if (rc) return rc; }   // (a lane that has to give its priority up does so here)
     ctx->lane_saved = ctx->stream;
     ctx->stream = ctx->lane;
     ctx->in_lane = true;
@@ -236,16 +313,16 @@ int vo_stats_gather(vo_ctx* ctx, void* rccl_comm, const vo_stats* local, vo_stat
     // ncclResult_t ncclAllReduce(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     // ncclFloat64 = 8, ncclSum = 0, ncclMax = 2 (rccl.h)
     typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
-    static allreduce_fn fn = nullptr;
-    if (!fn) {
-        fn = (allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");       // the RCCL the host process already holds
-        if (!fn) {
+    static const allreduce_fn fn = [] {   // resolved once (thread-safe static initialisation)
+        allreduce_fn f = (allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");       // the RCCL the host process already holds
+        if (!f) {
             void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
             if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (h) fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
+            if (h) f = (allreduce_fn)dlsym(h, "ncclAllReduce");
         }
-        if (!fn) { ctx->last_error = "vo_stats_gather: no RCCL in the process and librccl.so cannot be loaded"; return VO_ERR_UNSUPPORTED; }
-    }
+        return f;
+    }();
+    if (!fn) { ctx->last_error = "vo_stats_gather: no RCCL in the process and librccl.so cannot be loaded"; return VO_ERR_UNSUPPORTED; }
     (void)hipSetDevice(ctx->device);
     double* d = (double*)ctx->d_counters;   // not the counters themselves: a 160-byte staging area behind them
     d += VO_COUNTER_SHARDS * 4;
@@ -325,7 +402,7 @@ static int frame_prepare(vo_ctx* ctx, vo_pyr* f, int nu, int nv, int levels) {
     }
     if (f->nus[levels - 1] < 2 || f->nvs[levels - 1] < 2) { ctx->last_error = "frame: too many pyramid levels for this image"; return VO_ERR_BAD_ARG; }
     if ((size_t)tot > f->cap) {
-        VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        VO_HIP_CHECK(ctx, vo_int_quiesce(ctx));
         if (f->I) (void)hipFree(f->I);
         f->I = nullptr; f->cap = 0;
         VO_HIP_CHECK(ctx, hipMalloc((void**)&f->I, tot * sizeof(float)));
@@ -443,7 +520,7 @@ static int frame_from_host(vo_ctx* ctx, const uint8_t* img, int nu, int nv, int 
     f->valid = false;
     { int rc = frame_await(ctx, f); if (rc) return rc; }   // a prefetch into this slot may still be running
     if (nbytes > f->img_cap) {
-        VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        VO_HIP_CHECK(ctx, vo_int_quiesce(ctx));
         if (f->img) (void)hipFree(f->img);
         f->img = nullptr; f->img_cap = 0;
         VO_HIP_CHECK(ctx, hipMalloc((void**)&f->img, nbytes));

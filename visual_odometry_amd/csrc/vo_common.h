@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "../../include/vo_hip.h"
@@ -54,7 +55,12 @@ struct vo_ctx {
     hipStream_t lane = nullptr, lane_saved = nullptr;
     hipEvent_t ev_lane_fork = nullptr, ev_lane_done = nullptr;
     bool in_lane = false, lane_pending = false;
-    bool lane_high_priority = false;   // vo_ctx_lane_priority: asked for before the lane exists
+    bool lane_high_priority = false;   // vo_ctx_lane_priority: asked for before the lane exists (and granted)
+    bool lane_is_high = false;         // the lane stream that exists was created with the high priority
+    // set (by whichever thread creates another ctx or a decode pool on this device) when the process stops being
+    // "one ctx alone on its GPU": the owner takes its lane back to the ctx stream's priority before the lane's next use
+    std::atomic<bool> lane_demote{false};
+    hipEvent_t ev_lane_guard = nullptr;   // out-of-lane users of lane-shared buffers wait for the lane's work so far
     struct vo_sel_pending* sel_pending = nullptr;  // vo_dev_select_begin .. vo_dev_select_finish
     uint64_t sel_gen[2] = {0, 0};   // bumped whenever a selection work area is handed out: work issued ahead into it
                                     // (look-ahead, open selections) is valid only while the number stands
@@ -111,7 +117,12 @@ int vo_launch_select_filter(vo_ctx* ctx, hipStream_t stream, int nu, int nv, int
 // stream waits for everything enqueued on the side stream so far
 int vo_int_side_ensure(vo_ctx* ctx);   // the side stream exists
 int vo_int_side_fork(vo_ctx* ctx);
-int vo_int_lane_ensure(vo_ctx* ctx);   // creates the ctx's lane stream (vo_ctx_lane_*) if it does not exist yet
+int vo_int_lane_ensure(vo_ctx* ctx);   // creates the ctx's lane stream (vo_ctx_lane_*) if it does not exist yet; demotes it when asked to
+// Every owner of HIP streams of the library on a device announces itself here (vo_ctx_create, vo_ingest_open): a
+// high-priority lane is only granted to, and only kept by, a ctx that is alone on its device (vo_ctx_lane_priority).
+void vo_int_register_streams(int device, vo_ctx* owner_or_null);
+// the ctx stream waits for whatever the lane has been given so far (no-op without a lane, or inside it)
+int vo_int_wait_for_lane(vo_ctx* ctx);
 int vo_int_side_join(vo_ctx* ctx);
 int vo_launch_select(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is_rows, const float* d_eu,
                      const float* d_ev, int n_exist, const vo_sel_opts* o, vo_sel_work* w, float* d_out_u,

@@ -470,6 +470,7 @@ int vo_ingest_open(vo_ctx* ctx, const char* const* paths, int n_paths, const vo_
         ctx->last_error = "vo_ingest_open: out of host memory";
         return VO_ERR_OOM;
     }
+    vo_int_register_streams(ctx->device, nullptr);   // a copy stream on this GPU: no high-priority lane beside it (vo_ctx_lane_priority)
     hipError_t e = hipStreamCreateWithFlags(&g->copy, hipStreamNonBlocking);
     for (auto& s : g->slots) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ready, hipEventDisableTiming);

@@ -926,14 +926,16 @@ constexpr int STATIC_MAX_DEVICES = 64;
 // object AND give it a global symbol the runtime can look up; with the attribute it stays a local symbol and
 // hipGetSymbolAddress aborts)
 static __device__ __align__(256) unsigned char scratch[STATIC_BYTES];
-static unsigned char* g_scratch_ptr[STATIC_MAX_DEVICES];   // per device: where that GPU's copy of `scratch` lives
+// per device: where that GPU's copy of `scratch` lives.  Atomic: contexts are created from any thread, and every thread
+// that resolves a device's entry stores the same address
+static std::atomic<unsigned char*> g_scratch_ptr[STATIC_MAX_DEVICES];
 
 int vo_static_scratch_resolve(int device) {
     if (device < 0 || device >= STATIC_MAX_DEVICES) return VO_ERR_BAD_ARG;
-    if (g_scratch_ptr[device]) return VO_OK;
+    if (g_scratch_ptr[device].load(std::memory_order_acquire)) return VO_OK;
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return VO_ERR_HIP;   // the current device's copy
-    g_scratch_ptr[device] = (unsigned char*)p;
+    g_scratch_ptr[device].store((unsigned char*)p, std::memory_order_release);
     return VO_OK;
 }
 
@@ -949,11 +951,11 @@ int vo_dev_p3p_ransac_static(vo_ctx* ctx, const double* d_xy, const double* d_X,
     }
     if (ctx->device < 0 || ctx->device >= STATIC_MAX_DEVICES) { ctx->last_error = "vo_dev_p3p_ransac_static: device index beyond the table"; return VO_ERR_UNSUPPORTED; }
     (void)hipSetDevice(ctx->device);
-    if (!g_scratch_ptr[ctx->device]) {   // vo_ctx_create resolves it; a ctx made before a reload of the table ends here
+    if (!g_scratch_ptr[ctx->device].load(std::memory_order_acquire)) {   // vo_ctx_create resolves it; a ctx made before a reload of the table ends here
         const int rc = vo_static_scratch_resolve(ctx->device);
         if (rc) { ctx->last_error = "vo_dev_p3p_ransac_static: hipGetSymbolAddress failed"; return rc; }
     }
-    unsigned char* base = g_scratch_ptr[ctx->device];   // never the array's name
+    unsigned char* base = g_scratch_ptr[ctx->device].load(std::memory_order_acquire);   // never the array's name
     vo_ransac_work w;
     w.Rt = (double*)base;
     w.cnt = (int32_t*)(base + STATIC_RT);
