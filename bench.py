@@ -266,7 +266,8 @@ def main():
         dist.barrier()
         stats = dist.gather_stats({"frames": 1, "keypoints_tracked": args.keypoints, "elapsed_s": 1.0 + rank})
         if rank == 0:
-            print(json.dumps({"rendezvous": "ok", "n_gpus": world, "frames": stats["frames"], "elapsed_s": stats["elapsed_s"]}))
+            print(json.dumps({"rendezvous": "ok", "n_gpus": world, "frames": stats["frames"], "elapsed_s": stats["elapsed_s"],
+                              "per_rank_ms_per_step": dist.per_rank_ms_per_step(stats, 1)}))
         dist.shutdown()
         return
 
@@ -399,6 +400,8 @@ def main():
                                        "detection issued ahead into that tail (VO_NO_LANE=1 / VO_NO_PREFETCH=1 switch them off)",
                            "keypoints_per_frame": args.keypoints, "hypotheses": args.hyp,
                            "parallelism": f"{world} independent sequence(s), one per GPU"},
+                # every rank's own time per step (min / max / each, rank order): ms_per_step above is the slowest rank's
+                "per_rank_ms_per_step": dist.per_rank_ms_per_step(stats, args.steps),
                 "valid_fraction": stats["keypoints_valid"] / (world * args.keypoints),
                 "stage_ms": stage_ms, "roofline": roof}
         if not args.no_cpu and world == 1:                # the CPU side-by-side belongs to the one-GPU line only

@@ -40,6 +40,8 @@ def test_two_rank_gloo_gather():
     assert o0 == o1                                    # every rank sees the same gathered record
     assert o0["frames"] == 30 and o0["keypoints_tracked"] == 3000 and o0["keypoints_valid"] == 1800
     assert o0["elapsed_s"] == 2.0 and o0["world"] == 2  # the job ends with its slowest rank
+    assert o0["per_rank_elapsed_s"] == [1.0, 2.0]      # ... and every rank's own time is in the record, in rank order
+    assert dist.per_rank_ms_per_step(o0, 10) == {"min": 100.0, "max": 200.0, "each": [100.0, 200.0]}
     assert sorted(s0 + s1) == list(range(11)) and not set(s0) & set(s1)
 
 
@@ -54,7 +56,7 @@ def test_assignment_is_balanced_and_deterministic():
 
 def test_single_process_gather_is_identity():
     out = dist.gather_stats({"frames": 3, "elapsed_s": 0.5})
-    assert out["frames"] == 3 and out["elapsed_s"] == 0.5 and out["world"] == 1
+    assert out["frames"] == 3 and out["elapsed_s"] == 0.5 and out["world"] == 1 and out["per_rank_elapsed_s"] == [0.5]
 
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -73,6 +75,7 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1                                   # one line, from rank 0
     out = json.loads(lines[0])
     assert out["rendezvous"] == "ok" and out["n_gpus"] == 2 and out["frames"] == 2 and out["elapsed_s"] == 2.0
+    assert out["per_rank_ms_per_step"] == {"min": 1000.0, "max": 2000.0, "each": [1000.0, 2000.0]}   # the line shows stragglers
 
 
 def test_a_failing_rank_fails_the_launch(tmp_path):

@@ -251,9 +251,11 @@ def test_response_kitti_size_bit_exact(ctx, scorer, fs):
     np.testing.assert_array_equal(got, ref)
 
 
-@pytest.mark.parametrize("keep,n_exist", [(100, 1500), (5000, 20000), (100, 0)])
+@pytest.mark.parametrize("keep,n_exist", [(100, 1500), (5000, 20000), (100, 0), (100, 50000), (5000, 50000)])
 def test_selection_kitti_size_bit_exact(ctx, keep, n_exist):
-    """Live options of modules/VisualOdometry.m:330-335 and the stress variant of SURVEY 8d."""
+    """Live options of modules/VisualOdometry.m:330-335 and the stress variant of SURVEY 8d; n_exist = 50000 is the
+    size bench.py's step runs the filter at (device.FrameWorkload: every tracked point is an existing point -- 50k
+    discs of radius 7 cover a KITTI frame many times over, so few corners or none survive; the oracle says which)."""
     img, _, _ = synth.frame_pair(seed=42, noise=1.0)
     eu, ev = synth.keypoints(n_exist, seed=43, border=0.0) if n_exist else (np.zeros(0), np.zeros(0))
     eu = eu.astype(np.float32); ev = ev.astype(np.float32)
@@ -263,7 +265,7 @@ def test_selection_kitti_size_bit_exact(ctx, keep, n_exist):
         np.testing.assert_array_equal(lin, rlin)
         np.testing.assert_array_equal(u, ru); np.testing.assert_array_equal(v, rv)
         np.testing.assert_array_equal(met, rmet)
-        assert len(lin) > 0
+        assert len(lin) > 0 or n_exist >= 50000
 
 
 def test_selection_ties_and_strict_distance(ctx):

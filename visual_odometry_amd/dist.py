@@ -59,9 +59,16 @@ def barrier():
 
 def gather_stats(local):
     """Sum the counters over ranks and take the MAX of elapsed_s (the job ends with its slowest
-    rank).  `local` maps STAT_KEYS to numbers; every rank gets the same dict back."""
+    rank).  `local` maps STAT_KEYS to numbers; every rank gets the same dict back.  Beside the maximum the record
+    carries every rank's own elapsed_s in rank order ("per_rank_elapsed_s": one all_gather of a double inside this
+    same collective), so that a scaling run shows its stragglers."""
     vals = torch.tensor([float(local.get(k, 0.0)) for k in STAT_KEYS], dtype=torch.float64, device=_device())
+    each = [float(local.get("elapsed_s", 0.0))]
     if dist.is_initialized():
+        mine = vals[STAT_KEYS.index("elapsed_s")].reshape(1).clone()
+        parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, mine)
+        each = [float(p.item()) for p in parts]
         sums = vals.clone()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         mx = vals.clone()
@@ -70,7 +77,14 @@ def gather_stats(local):
         vals[STAT_KEYS.index("elapsed_s")] = mx[STAT_KEYS.index("elapsed_s")]
     out = {k: float(v) for k, v in zip(STAT_KEYS, vals.tolist())}
     out["world"] = dist.get_world_size() if dist.is_initialized() else 1
+    out["per_rank_elapsed_s"] = each
     return out
+
+
+def per_rank_ms_per_step(stats, steps):
+    """what bench.py's line carries for N > 1: every rank's own time per step, and their extremes"""
+    each = [1e3 * e / steps for e in stats["per_rank_elapsed_s"]]
+    return {"min": min(each), "max": max(each), "each": each}
 
 
 def shutdown():
