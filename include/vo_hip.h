@@ -149,7 +149,9 @@ int vo_timer_laps_ms(vo_ctx* ctx, float* total_ms, int* laps);
 /* ==== host-pointer entry points (what the MEX gateways bind) ==== */
 
 /* KLTTracker.track, modules/KLTTracker.m:22-41.  pts: N x 2 [x y]; outputs follow the class of
- * the input points (pts_is_double).  N = 0 returns VO_OK and touches nothing (:33-36). */
+ * the input points (pts_is_double).  N = 0 returns VO_OK and touches nothing (:33-36).
+ * out_scores may be NULL: the third output of track is then not computed (the live pipeline discards it,
+ * modules/VisualOdometry.m:71,278 `[.., .., ~] = obj.tracker.track(...)`; a gateway called with nargout < 3 passes NULL). */
 int vo_klt_track(vo_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int H, int W, vo_layout lay,
                  const void* pts_xy, int N, int pts_is_double, const vo_klt_opts* opts,
                  void* out_pts_xy, uint8_t* out_valid, void* out_scores);
@@ -232,7 +234,9 @@ int vo_essential_ransac(vo_ctx* ctx, vo_layout lay, const double* pts0, const do
 /* build the float pyramid of a device image into a frame slot (no gradient planes: the tracker differentiates the
  * sampled template) */
 int vo_dev_frame_build(vo_ctx* ctx, int slot, const uint8_t* d_img, int nu, int nv, int levels);
-/* track slot_a -> slot_b; wu/wv = window along u / v */
+/* track slot_a -> slot_b; wu/wv = window along u / v.  d_score (and d_fb_err) may be NULL: the match score costs two
+ * more patch stagings and a window pass per keypoint and is skipped when nobody reads it (modules/VisualOdometry.m:71,278
+ * discard it) */
 int vo_dev_klt_track(vo_ctx* ctx, int slot_a, int slot_b, const double* d_pu, const double* d_pv, int n,
                      int wu, int wv, int max_iters, double eps, double max_bidir_err, double* d_qu,
                      double* d_qv, uint8_t* d_valid, float* d_score, float* d_fb_err);

@@ -475,7 +475,7 @@ int vo_dev_klt_track(vo_ctx* ctx, int sa, int sb, const double* d_pu, const doub
                      float* d_score, float* d_fb) {
     if (!ctx || sa < 0 || sa >= VO_NUM_FRAME_SLOTS || sb < 0 || sb >= VO_NUM_FRAME_SLOTS) return VO_ERR_BAD_ARG;
     if (n == 0) return VO_OK;
-    if (n < 0 || !d_pu || !d_pv || !d_qu || !d_qv || !d_valid || !d_score) return VO_ERR_BAD_ARG;
+    if (n < 0 || !d_pu || !d_pv || !d_qu || !d_qv || !d_valid) return VO_ERR_BAD_ARG;   // d_score may be NULL: scores not wanted
     if (!ctx->frames[sa].valid || !ctx->frames[sb].valid) { ctx->last_error = "klt: frame slot not built"; return VO_ERR_BAD_ARG; }
     if (eps <= 0) eps = 0.01;
     (void)hipSetDevice(ctx->device);
@@ -548,7 +548,7 @@ int vo_klt_track(vo_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int H, i
                  uint8_t* out_valid, void* out_scores) {
     if (!ctx || !o) return VO_ERR_BAD_ARG;
     if (N == 0) return VO_OK; // modules/KLTTracker.m:33-36: outputs stay the caller's typed empties
-    if (N < 0 || !img1 || !img2 || !pts_xy || !out_pts_xy || !out_valid || !out_scores || H <= 0 || W <= 0) return VO_ERR_BAD_ARG;
+    if (N < 0 || !img1 || !img2 || !pts_xy || !out_pts_xy || !out_valid || H <= 0 || W <= 0) return VO_ERR_BAD_ARG;   // out_scores may be NULL
     (void)hipSetDevice(ctx->device);
     const int nu = lay.col_major ? H : W, nv = lay.col_major ? W : H;
     const int wu = lay.col_major ? o->block_h : o->block_w, wv = lay.col_major ? o->block_w : o->block_h;
@@ -572,6 +572,7 @@ int vo_klt_track(vo_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int H, i
     if ((rc = dbuf(ctx, SB_QU, 2 * (size_t)N, &d_q))) return rc;
     if ((rc = dbuf(ctx, SB_VALID, (size_t)N, &d_valid))) return rc;
     if ((rc = dbuf(ctx, SB_SCORE, (size_t)N, &d_score))) return rc;
+    if (!out_scores) d_score = nullptr;   // the caller discards the scores (modules/VisualOdometry.m:71,278 do): they are not computed
     VO_HIP_CHECK(ctx, hipMemcpyAsync(d_p, h.data(), 2 * (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     const double eps = o->eps > 0 ? o->eps : 0.01;
     rc = vo_launch_klt(ctx, &ctx->frames[sa], &ctx->frames[sb], d_p, d_p + N, N, wu, wv, o->max_iters, eps,
@@ -580,7 +581,7 @@ int vo_klt_track(vo_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int H, i
     std::vector<float> hs((size_t)N);
     VO_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), d_q, 2 * (size_t)N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP_CHECK(ctx, hipMemcpyAsync(out_valid, d_valid, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP_CHECK(ctx, hipMemcpyAsync(hs.data(), d_score, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (d_score) VO_HIP_CHECK(ctx, hipMemcpyAsync(hs.data(), d_score, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < N; ++i) {
         const double u = h[i] + base, v = h[(size_t)N + i] + base;
@@ -588,10 +589,10 @@ int vo_klt_track(vo_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int H, i
         const size_t ix = lay.col_major ? (size_t)i : 2 * (size_t)i, iy = lay.col_major ? (size_t)N + i : 2 * (size_t)i + 1;
         if (pts_is_double) {
             ((double*)out_pts_xy)[ix] = x; ((double*)out_pts_xy)[iy] = y;
-            ((double*)out_scores)[i] = (double)hs[i];
+            if (out_scores) ((double*)out_scores)[i] = (double)hs[i];
         } else {
             ((float*)out_pts_xy)[ix] = (float)x; ((float*)out_pts_xy)[iy] = (float)y;
-            ((float*)out_scores)[i] = hs[i];
+            if (out_scores) ((float*)out_scores)[i] = hs[i];
         }
     }
     return VO_OK;

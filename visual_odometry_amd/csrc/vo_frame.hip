@@ -811,7 +811,7 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     // order.  The number M of those stays on the device (counts[6]): the pose step, the reprojection filter and the
     // compaction are sized by the capacity and read M themselves.
     if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->kp[s], st->kp[s] + cl, cl, o.klt.block_w, o.klt.block_h,
-                            o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, st->score, nullptr, st->sizes + 0))) { leave_lane(); return rc; }
+                            o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, /* scores: processFrame discards them, :278 */ nullptr, nullptr, st->sizes + 0))) { leave_lane(); return rc; }
     stamp(sl, 1);
     {   // (the frame's counters and tombstones are cleared by the same launch)
         TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
@@ -853,7 +853,7 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     stamp(sm, 5);
     // :71 track the candidates: points from the state, results straight into the candidates' work arrays
     if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->cu[s], st->cu[s] + cc, cc, o.klt.block_w, o.klt.block_h,
-                            o.klt.max_iters, eps, o.klt.max_bidir_err, st->cq, st->cq + cc, st->cvalid, st->score + cl, nullptr, st->sizes + 1))) return rc;
+                            o.klt.max_iters, eps, o.klt.max_bidir_err, st->cq, st->cq + cc, st->cvalid, /* :71 `~` */ nullptr, nullptr, st->sizes + 1))) return rc;
     stamp(sm, 6);
     if (sl != sm) ST_CHECK(hipStreamWaitEvent(sm, st->ev_pose, 0));
     stamp(sm, 7);

@@ -32,7 +32,7 @@ struct LKArgs {
     int nu0, nv0;
     int levels, wu, wv, npx, max_iters, n;
     float eps2;
-    double max_bidir, flat_thr; // flat_thr = 2 * npx * VO_MIN_EIG
+    double max_bidir, flat_thr; // flat_thr = 64 * 2 * npx * VO_MIN_EIG: the flat test's bound on sums of the x8 gradients
     const double *pu, *pv;
     double *qu, *qv;
     uint8_t* valid;
@@ -64,6 +64,12 @@ __device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? l
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ float dpp_mov(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROWMASK, 0xf, false));
+}
+// the same with bound_ctrl: a lane without a source lane reads 0 and the destination needs no prior value (one
+// v_mov less per use than the form above, whose untouched lanes keep `old`)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_z(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
 }
 // sum over the 64 lanes, result uniform
 __device__ __forceinline__ float wave_sum(float x) {
@@ -295,11 +301,11 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                     }
                     float ectr;   // the centre row's sample in column BW (the template intensity of pixel BW - 1)
                     if constexpr (SHARE) {
-                        VD[BW] = dpp_mov<0x130, 0xf>(VD[0]);       // wave_shl:1 -- lane i reads lane i + 1
-                        VD[BW + 1] = dpp_mov<0x130, 0xf>(VD[1]);
-                        VS[BW] = dpp_mov<0x130, 0xf>(VS[0]);
-                        VS[BW + 1] = dpp_mov<0x130, 0xf>(VS[1]);
-                        ectr = dpp_mov<0x130, 0xf>(e1[0]);
+                        VD[BW] = dpp_mov_z<0x130>(VD[0]);       // wave_shl:1 -- lane i reads lane i + 1
+                        VD[BW + 1] = dpp_mov_z<0x130>(VD[1]);
+                        VS[BW] = dpp_mov_z<0x130>(VS[0]);
+                        VS[BW + 1] = dpp_mov_z<0x130>(VS[1]);
+                        ectr = dpp_mov_z<0x130>(e1[0]);
                     } else {
                         ectr = e1[BW];
                     }
@@ -318,31 +324,42 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             }
             ++setups;
         }
-        // sums of the x8 gradients: G = sums / 64
+        // sums of the x8 gradients: S = 64 G
         float s5in[5] = {sxx, sxy, syy, ctu, ctv}, s5[5];
         wave_sums<5>(s5in, s5);
-        const double Guu = (double)s5[0] * 0.015625, Guv = (double)s5[1] * 0.015625, Gvv = (double)s5[2] * 0.015625;
         const float CTu = s5[3], CTv = s5[4];
-        const double dif = Guu - Gvv;
-        // mineig(G) / npx >= VO_MIN_EIG without the division: 2 * mineig(G) >= 2 * npx * VO_MIN_EIG
-        // explicit fma where a sum of two products could be fused either way: under -ffp-contract=fast the compiler's
-        // pick changed with unrelated edits, and with it the last bits of 5 % of the tracks (scripts/ab_bits.py)
-        const double mineig2 = (Guu + Gvv) - sqrt(fma(dif, dif, 4.0 * (Guv * Guv)));
-        const double det = fma(Guu, Gvv, -(Guv * Guv));
+        // Flat test mineig(G) / npx >= VO_MIN_EIG without the eigenvalue: with t = 64 * 2 npx VO_MIN_EIG (LKArgs::flat_thr)
+        //   2 mineig(S) >= t  <=>  (2 Suu - t) + (2 Svv - t) >= 0  and  (2 Suu - t)(2 Svv - t) >= (2 Suv)^2
+        // (the characteristic polynomial of S at t / 2 is non-negative left of both eigenvalues).  A handful of fp64
+        // operations on wave-uniform values -- the product difference cancels for edge-like windows, which is why it is
+        // not fp32 -- instead of an fp64 square root and an fp64 division (~45 double-rate instructions per set-up,
+        // eight set-ups a keypoint; an fp64 instruction costs the vector unit 1.6 fp32 ones).
+        const double Suu = (double)s5[0], Suv = (double)s5[1], Svv = (double)s5[2];
+        const double ea = fma(2.0, Suu, -a.flat_thr), eb = fma(2.0, Svv, -a.flat_thr);
+        const double suv2 = Suv * Suv;
+        const bool flat = !((ea + eb >= 0.0) && (fma(ea, eb, -4.0 * suv2) >= 0.0));
         float du = 0, dv = 0;
-        const bool flat = !(mineig2 >= a.flat_thr);
         if (flat) {
             if (l == 0) flags |= 2;
         } else {
-            // the residual sums carry the x8 of the gradients: 1/8 goes into the inverse
-            const double idet = 0.125 / det;
-            const float iuu = unif((float)(Gvv * idet)), iuv = unif((float)(-Guv * idet)), ivv = unif((float)(Guu * idet));
+            // inv(G) / 8 (the residual sums carry the x8 of the gradients) = 8 adj(S) / det(S): the determinant in fp64 (it
+            // cancels too), its reciprocal in fp32 with one Newton step (the update needs no more: the fixed point of the
+            // iteration does not depend on the inverse, only the path to it)
+            const float detS = (float)fma(Suu, Svv, -suv2);
+            float rdet = __builtin_amdgcn_rcpf(detS);
+            rdet = rdet * fmaf(-detS, rdet, 2.0f);
+            const float r8 = 8.0f * rdet;
+            const float iuu = unif(s5[2] * r8), iuv = unif(-s5[1] * r8), ivv = unif(s5[0] * r8);
             // position = (ibu + fbu + du, ibv + fbv + dv): integer base + float remainder
             const double bu0 = plu + gu, bv0 = plv + gv;
             const double fbu0 = floor(bu0), fbv0 = floor(bv0);
             const int ibu = uni((int)fbu0), ibv = uni((int)fbv0);
             const float fbu = unif((float)(bu0 - fbu0)), fbv = unif((float)(bv0 - fbv0));
-            const float sf = (float)(1 << l), umax = (float)(nu0 - 1), vmax = (float)(nv0 - 1);
+            // N4 lost test, (ibu + tu) 2^l inside [0, nu0 - 1], as bounds on tu itself (2^l is a power of two and the base
+            // an integer: the bounds are exact)
+            const float isf = __builtin_ldexpf(1.0f, -l);
+            const float tlo_u = -(float)ibu, thi_u = (float)(nu0 - 1) * isf - (float)ibu;
+            const float tlo_v = -(float)ibv, thi_v = (float)(nv0 - 1) * isf - (float)ibv;
             bool staged = false, cell = false;
             int pou = 0, pov = 0, ciu = 0, civ = 0;
             // sum J*(Tu,Tv) is bilinear in the sub-pixel fractions: inside one pixel cell it is the
@@ -350,11 +367,9 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             // They are computed once per visited cell; an iteration inside the cell is scalar work.
             // residual inside the cell: B = k0 - fu*ka - fv*(kb + fu*kc), per gradient
             float ku0 = 0, kua = 0, kub = 0, kuc = 0, kv0 = 0, kva = 0, kvb = 0, kvc = 0;
-            const float fibu = (float)ibu, fibv = (float)ibv;
             for (int it = 0; it < a.max_iters; ++it) {
                 const float tu = fbu + du, tv = fbv + dv;
-                const float cu0 = (fibu + tu) * sf, cv0 = (fibv + tv) * sf; // level-0 position (N4 lost test)
-                if (__builtin_amdgcn_ballot_w64(!(cu0 >= 0.0f && cu0 <= umax && cv0 >= 0.0f && cv0 <= vmax))) {
+                if (__builtin_amdgcn_ballot_w64(!(tu >= tlo_u && tu <= thi_u && tv >= tlo_v && tv <= thi_v))) {
                     flags |= 1;
                     break;
                 }
@@ -482,7 +497,9 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     return flags;
 }
 
-template <class C, bool W41>
+// SCORE: the N5 match score is computed (two more patch stagings and a window pass per keypoint); without it -- the
+// caller passed no score array: modules/VisualOdometry.m:71,278 discard the third output of track -- it is skipped
+template <class C, bool W41, bool SCORE>
 __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
     __shared__ __attribute__((aligned(16))) float patch[C::PW * C::PH];
     const int lane = threadIdx.x, kp = blockIdx.x;
@@ -516,7 +533,7 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
     unsigned iters = 0, setups = 0, cells = 0;
     double fu, fv, bu = 0, bv = 0;
     float ssd, ssd2;
-    const int fl = lk_dir<C, true, W41>(a, a.A, a.B, p0u, p0v, patch, lane, lr, lq, lbase, wmask, fu, fv, ssd, iters, setups, cells);
+    const int fl = lk_dir<C, SCORE, W41>(a, a.A, a.B, p0u, p0v, patch, lane, lr, lq, lbase, wmask, fu, fv, ssd, iters, setups, cells);
     bool ok = (fl == 0);
     float fb = __builtin_nanf("");
     if (!(fl & 1) && a.max_bidir >= 0.0) {
@@ -532,12 +549,14 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
     if (lane == 0) {
         a.qu[kp] = fu; a.qv[kp] = fv;
         a.valid[kp] = ok ? 1 : 0;
-        float sc = 0.0f;
-        if (!(fl & 1)) {
-            sc = 1.0f - sqrtf(ssd / (float)a.npx) / 255.0f;
-            sc = fminf(fmaxf(sc, 0.0f), 1.0f);
+        if constexpr (SCORE) {
+            float sc = 0.0f;
+            if (!(fl & 1)) {
+                sc = 1.0f - sqrtf(ssd / (float)a.npx) / 255.0f;
+                sc = fminf(fmaxf(sc, 0.0f), 1.0f);
+            }
+            a.score[kp] = sc;
         }
-        a.score[kp] = sc;
         if (a.fb) a.fb[kp] = fb;
         unsigned long long* cnt = a.counters + 4 * (kp & (VO_COUNTER_SHARDS - 1));
         atomicAdd(&cnt[0], (unsigned long long)iters);
@@ -549,11 +568,16 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
     }
 }
 
+template <class C, bool SCORE>
+void launch_s(const LKArgs& a, hipStream_t st) {
+    // the window that cuts only the last column / row of blocks the way WinMask<true> assumes
+    if (a.wu == (C::LU - 1) * C::BW + 1 && a.wv == C::LV * C::BH - 1) hipLaunchKernelGGL((k_lk<C, true, SCORE>), dim3(a.n), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_lk<C, false, SCORE>), dim3(a.n), dim3(64), 0, st, a);
+}
 template <class C>
 void launch(const LKArgs& a, hipStream_t st) {
-    // the window that cuts only the last column / row of blocks the way WinMask<true> assumes
-    if (a.wu == (C::LU - 1) * C::BW + 1 && a.wv == C::LV * C::BH - 1) hipLaunchKernelGGL((k_lk<C, true>), dim3(a.n), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_lk<C, false>), dim3(a.n), dim3(64), 0, st, a);
+    if (a.score) launch_s<C, true>(a, st);
+    else launch_s<C, false>(a, st);
 }
 
 } // namespace
@@ -570,7 +594,7 @@ int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d
     a.levels = A->levels; a.wu = wu; a.wv = wv;
     a.npx = wu * wv; a.max_iters = max_iters; a.n = n;
     a.eps2 = (float)(eps * eps); a.max_bidir = max_bidir;
-    a.flat_thr = 2.0 * (double)a.npx * (double)VO_MIN_EIG;
+    a.flat_thr = 64.0 * 2.0 * (double)a.npx * (double)VO_MIN_EIG;
     a.pu = d_pu; a.pv = d_pv; a.qu = d_qu; a.qv = d_qv; a.valid = d_valid; a.score = d_score; a.fb = d_fb;
     a.counters = ctx->d_counters; a.n_dev = d_n;
     if (wu <= CfgS::MAXU && wv <= CfgS::MAXV) launch<CfgS>(a, ctx->stream);

@@ -32,6 +32,7 @@ class FrameWorkload:
         # (modules/VisualOdometry.m: the pose step :285-289 needs the landmark tracks of :278 only, the candidate
         # tracking of :71 neither).  VO_NO_LANE=1: one tracking launch over both sets, then the pose (A/B switch).
         self.lane = not os.environ.get("VO_NO_LANE")
+        self.scores = bool(os.environ.get("VO_KLT_SCORES"))      # the frame step discards the tracker's scores
         # lane_priority: the lane as a high-priority stream (vo_ctx_lane_priority) -- for a process with one ctx on a GPU of
         # its own (bench.py); refused, and ignored here, once the ctx's lane exists
         if lane_priority and self.lane:
@@ -57,7 +58,7 @@ class FrameWorkload:
         self.pa = torch.cat([pts(self.nl, seed + 1024), pts(self.nc, seed + 2048)], 1).contiguous()
         self.qa = torch.empty_like(self.pa)
         self.va = torch.empty(self.nl + self.nc, dtype=torch.uint8, device=self.dev)
-        self.sa = torch.empty(self.nl + self.nc, dtype=torch.float32, device=self.dev)
+        self.sa = torch.zeros(self.nl + self.nc, dtype=torch.float32, device=self.dev)   # stays zero when the scores are not asked for
         self.pl, self.pc = self.pa[:, :self.nl], self.pa[:, self.nl:]
         self.ql, self.qc = self.qa[:, :self.nl], self.qa[:, self.nl:]
         self.vl, self.vc = self.va[:self.nl], self.va[self.nl:]
@@ -100,18 +101,20 @@ class FrameWorkload:
         self.ctx.call("vo_dev_frame_build", slot, _p(self.frames[frame]), self.nu, self.nv, self.levels)
 
     def track(self, a, b, p, q, valid, score):
+        """score: None = not wanted, as in the frame step the workload restates -- modules/VisualOdometry.m:278 and :71
+        take `[points, validity, ~]` from the tracker (VO_KLT_SCORES=1 computes them all the same: A/B switch)"""
         n = p.shape[1]
         self.ctx.call("vo_dev_klt_track", a, b, _p(p[0]), _p(p[1]), n, self.block, self.block, self.max_iters,
                       C.c_double(self.eps), C.c_double(self.max_bidir), _p(q[0]), _p(q[1]), _p(valid), _p(score), None)
 
     def track_all(self, a, b):
-        self.track(a, b, self.pa, self.qa, self.va, self.sa)
+        self.track(a, b, self.pa, self.qa, self.va, self.sa if self.scores else None)
 
     def track_landmarks(self, a, b):
-        self.track(a, b, self.pl, self.ql, self.vl, self.sl)
+        self.track(a, b, self.pl, self.ql, self.vl, self.sl if self.scores else None)
 
     def track_candidates(self, a, b):
-        self.track(a, b, self.pc, self.qc, self.vc, self.sc)
+        self.track(a, b, self.pc, self.qc, self.vc, self.sc if self.scores else None)
 
     def pose(self):
         self.ctx.call("vo_dev_p3p_ransac", _p(self.rs_xy), _p(self.rs_X), self.nl, _p(self.K), C.byref(self.rs_opts),
