@@ -240,6 +240,22 @@ int vo_dev_frame_build(vo_ctx* ctx, int slot, const uint8_t* d_img, int nu, int 
 int vo_dev_klt_track(vo_ctx* ctx, int slot_a, int slot_b, const double* d_pu, const double* d_pv, int n,
                      int wu, int wv, int max_iters, double eps, double max_bidir_err, double* d_qu,
                      double* d_qv, uint8_t* d_valid, float* d_score, float* d_fb_err);
+/* The frame's two track calls (modules/VisualOdometry.m:278 landmarks, :71 candidates) as ONE launch whose first n_head
+ * points are a set of their own: they are dispatched first, and what vo_dev_wait_head releases starts when the last of
+ * them is done -- while the rest of the launch is still running.  No counterpart in the reference (MATLAB runs :278-289
+ * and :71 one after the other); it is how the pose chain, which needs the landmark tracks only, runs beside the candidate
+ * track without a stream priority: order, not priority.  Points n_head .. n-1 behave as in vo_dev_klt_track.  Call it on
+ * the ctx stream (outside the lane), THEN open the lane and call vo_dev_wait_head there, then the head's consumers:
+ *     vo_dev_klt_track_head(ctx, ...);  vo_ctx_lane_begin(ctx);  vo_dev_wait_head(ctx);  vo_dev_p3p_ransac(ctx, ...);
+ *     vo_ctx_lane_end(ctx);  ...  vo_ctx_lane_join(ctx);
+ * vo_dev_wait_head enqueues a one-wave kernel that polls a word the launch's last head keypoint sets; it gives up after
+ * ~0.25 s (vo_dev_head_timed_out then reports 1, and the consumers ran on unfinished data).  The head's outputs are
+ * written with write-through stores, so kernels that start behind the wait read them although the launch has not ended. */
+int vo_dev_klt_track_head(vo_ctx* ctx, int slot_a, int slot_b, const double* d_pu, const double* d_pv, int n_head, int n,
+                          int wu, int wv, int max_iters, double eps, double max_bidir_err, double* d_qu, double* d_qv,
+                          uint8_t* d_valid, float* d_score, float* d_fb_err);
+int vo_dev_wait_head(vo_ctx* ctx);
+int vo_dev_head_timed_out(vo_ctx* ctx, int* timed_out);   /* synchronises the ctx stream */
 /* u_is_rows: 1 when the u axis is the image's row (y) axis (MATLAB layout) */
 int vo_dev_select_candidates(vo_ctx* ctx, const uint8_t* d_img, int nu, int nv, int u_is_rows,
                              const float* d_eu, const float* d_ev, int n_exist, const vo_sel_opts* opts,

@@ -143,21 +143,83 @@ def test_steps_with_work_issued_ahead_equal_serial_steps(ctx):
     try:
         kw = dict(nv=120, nu=160, n_frames=4, num_hyp=64, levels=3, block=21, max_iters=30, keep=40, seed=77)
         serial = FrameWorkload(ctx, 300, 200, ahead=False, **kw)
-        ahead = FrameWorkload(other, 300, 200, ahead=True, **kw)
+        ahead = FrameWorkload(other, 300, 200, ahead=True, head=True, **kw)     # one tracking launch, the landmarks its head
+        third = _lib.Context(0)
+        two = FrameWorkload(third, 300, 200, ahead=True, head=False, **kw)      # two tracking launches on two streams
         for k in range(11):
-            serial.step(); ahead.step()
-            serial.sync(); ahead.sync()
+            serial.step(); ahead.step(); two.step()
+            serial.sync(); ahead.sync(); two.sync()
             for name in ("qa", "va", "sa", "rs_out", "rs_inl", "tr_X", "tr_val", "sel_cnt", "sel_u", "sel_v", "sel_lin"):
-                a, b = getattr(serial, name), getattr(ahead, name)
-                if name.startswith("sel_") and name != "sel_cnt":
-                    m = int(serial.sel_cnt.item())
-                    a, b = a[:m], b[:m]
-                assert torch.equal(a, b) or np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True), (k, name)
+                for wl in (ahead, two):
+                    a, b = getattr(serial, name), getattr(wl, name)
+                    if name.startswith("sel_") and name != "sel_cnt":
+                        m = int(serial.sel_cnt.item())
+                        a, b = a[:m], b[:m]
+                    assert torch.equal(a, b) or np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True), (k, name)
             assert int(serial.sel_cnt.item()) > 0
+        t = C.c_int(-1)
+        other.call("vo_dev_head_timed_out", C.byref(t))
+        assert t.value == 0                # no wait for a head ever gave up
         ahead.drain()                      # what was begun ahead is finished; single stages work again
         ahead.select(1); ahead.sync()
+        two.drain(); two.sync(); third.close()
     finally:
         other.close()
+
+
+def test_head_of_a_tracking_launch(ctx):
+    """vo_dev_klt_track_head: same results as vo_dev_klt_track for every split of the points (head 0, a few, all), with
+    a consumer of the head's results released by vo_dev_wait_head on the lane while the rest of the launch runs; the
+    calls that make no sense are refused."""
+    import torch
+    nv, nu = 120, 160
+    img1, img2, _ = synth.frame_pair(nv=nv, nu=nu, seed=91, shift=(1.2, -0.7))
+    pu, pv = synth.keypoints(700, nv=nv, nu=nu, seed=92, border=12)
+    d1 = torch.from_numpy(img1).cuda(); d2 = torch.from_numpy(img2).cuda()
+    p = torch.from_numpy(np.stack([pu, pv])).cuda()
+    c = _lib.Context(0)
+    try:
+        with pytest.raises(_lib.VoError, match="no vo_dev_klt_track_head"):
+            c.call("vo_dev_wait_head")
+        c.call("vo_dev_frame_build", 0, ptr(d1), nu, nv, 3); c.call("vo_dev_frame_build", 1, ptr(d2), nu, nv, 3)
+
+        def run(n_head):
+            q = torch.full_like(p, -1.0); valid = torch.full((p.shape[1],), 7, dtype=torch.uint8, device="cuda")
+            copy = torch.full((2, max(n_head or 0, 1)), -2.0, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            args = (ptr(p[0]), ptr(p[1]))
+            tail = (21, 21, 30, C.c_double(0.01), C.c_double(2.0), ptr(q[0]), ptr(q[1]), ptr(valid), None, None)
+            if n_head is None:
+                c.call("vo_dev_klt_track", 0, 1, *args, p.shape[1], *tail)
+            else:
+                c.call("vo_ctx_lane_begin"); c.call("vo_ctx_lane_end")
+                c.call("vo_dev_klt_track_head", 0, 1, *args, n_head, p.shape[1], *tail)
+                with pytest.raises(_lib.VoError):                       # inside the lane the launch is refused
+                    c.call("vo_ctx_lane_resume")
+                    try:
+                        c.call("vo_dev_klt_track_head", 0, 1, *args, n_head, p.shape[1], *tail)
+                    finally:
+                        c.call("vo_ctx_lane_end")
+                if n_head > 0:
+                    c.call("vo_ctx_lane_resume")
+                    c.call("vo_dev_wait_head")
+                    # a consumer on the lane: copies the head's results while the rest of the launch may still run
+                    with torch.cuda.stream(torch.cuda.ExternalStream(c.lib.vo_ctx_get_stream(c.h))):
+                        copy.copy_(q[:, :n_head])
+                    c.call("vo_ctx_lane_end"); c.call("vo_ctx_lane_join")
+            c.sync(); torch.cuda.synchronize()
+            return q.cpu().numpy(), valid.cpu().numpy(), copy.cpu().numpy()
+        want = run(None)
+        for n_head in (0, 1, 37, 350, 700):
+            q, valid, copy = run(n_head)
+            assert np.array_equal(q, want[0], equal_nan=True) and np.array_equal(valid, want[1]), n_head
+            if n_head:
+                assert np.array_equal(copy, want[0][:, :n_head], equal_nan=True), n_head    # the consumer saw finished results
+        t = C.c_int(-1)
+        c.call("vo_dev_head_timed_out", C.byref(t))
+        assert t.value == 0
+    finally:
+        c.close()
 
 
 def test_response_entry_points_leave_open_selections_alone(ctx):

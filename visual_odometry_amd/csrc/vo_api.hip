@@ -95,8 +95,8 @@ int vo_ctx_create(int device, vo_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc((void**)&c->d_counters, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long) + 512) != hipSuccess   /* + vo_stats_gather's staging (256 B) + the pose step's ticket (256 B) */ ||
-        hipMemset(c->d_counters, 0, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long) + 512) != hipSuccess) {
+        hipMalloc((void**)&c->d_counters, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long) + 768) != hipSuccess   /* + vo_stats_gather's staging (256 B) + the pose step's ticket (256 B) + the head words of a tracking launch (256 B) */ ||
+        hipMemset(c->d_counters, 0, VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long) + 768) != hipSuccess) {
         vo_ctx_destroy(c);
         return VO_ERR_HIP;
     }
@@ -484,6 +484,45 @@ int vo_dev_klt_track(vo_ctx* ctx, int sa, int sb, const double* d_pu, const doub
     if (rc) return rc;
     return vo_launch_klt(ctx, &ctx->frames[sa], &ctx->frames[sb], d_pu, d_pv, n, wu, wv, max_iters, eps, max_bidir,
                          d_qu, d_qv, d_valid, d_score, d_fb);
+}
+
+int vo_dev_klt_track_head(vo_ctx* ctx, int sa, int sb, const double* d_pu, const double* d_pv, int n_head, int n, int wu, int wv,
+                          int max_iters, double eps, double max_bidir, double* d_qu, double* d_qv, uint8_t* d_valid,
+                          float* d_score, float* d_fb) {
+    if (!ctx || sa < 0 || sa >= VO_NUM_FRAME_SLOTS || sb < 0 || sb >= VO_NUM_FRAME_SLOTS) return VO_ERR_BAD_ARG;
+    if (n < 0 || n_head < 0 || n_head > n) return VO_ERR_BAD_ARG;
+    if (ctx->in_lane) { ctx->last_error = "vo_dev_klt_track_head: call it outside the lane (the lane is where the head's consumers go)"; return VO_ERR_BAD_ARG; }
+    if (n == 0) return VO_OK;
+    if (!d_pu || !d_pv || !d_qu || !d_qv || !d_valid) return VO_ERR_BAD_ARG;
+    if (!ctx->frames[sa].valid || !ctx->frames[sb].valid) { ctx->last_error = "klt: frame slot not built"; return VO_ERR_BAD_ARG; }
+    if (eps <= 0) eps = 0.01;
+    (void)hipSetDevice(ctx->device);
+    int rc = frame_await(ctx, &ctx->frames[sa]);
+    if (!rc) rc = frame_await(ctx, &ctx->frames[sb]);
+    if (rc) return rc;
+    rc = vo_launch_klt(ctx, &ctx->frames[sa], &ctx->frames[sb], d_pu, d_pv, n, wu, wv, max_iters, eps, max_bidir, d_qu, d_qv,
+                       d_valid, d_score, d_fb, nullptr, n_head);
+    if (!rc) ctx->head_open = n_head > 0;
+    return rc;
+}
+
+int vo_dev_wait_head(vo_ctx* ctx) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    // Only behind a head that HAS been enqueued: a waiting kernel in front of its launch in a shared hardware queue
+    // would sit there until its time-out.  (The launch itself is on another stream: the order of the two calls is the
+    // order of the packets wherever the two streams share a queue.)
+    if (!ctx->head_open) { ctx->last_error = "vo_dev_wait_head: no vo_dev_klt_track_head launch to wait for"; return VO_ERR_BAD_ARG; }
+    (void)hipSetDevice(ctx->device);
+    return vo_launch_wait_head(ctx);
+}
+
+int vo_dev_head_timed_out(vo_ctx* ctx, int* timed_out) {
+    if (!ctx || !timed_out) return VO_ERR_BAD_ARG;
+    unsigned w = 0;
+    VO_HIP_CHECK(ctx, hipMemcpyAsync(&w, reinterpret_cast<unsigned*>(vo_int_head_words(ctx)) + 2, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *timed_out = (int)w;
+    return VO_OK;
 }
 
 // content hash for the host-API pyramid cache (the reference calls track twice per frame on the

@@ -69,8 +69,14 @@ struct vo_ctx {
     uint64_t clock = 0;
     unsigned long long* d_counters = nullptr; // VO_COUNTER_SHARDS x 4 u64
     vo_buf scratch[20];                        // purpose-indexed scratch (see vo_api.hip; [16] = vo_rgb2gray staging, [17] = second selection set, [18] = response / greedy entry points)
+    bool head_open = false;    // a vo_dev_klt_track_head launch has been enqueued (vo_dev_wait_head may follow)
+    unsigned head_epoch = 0;   // vo_dev_klt_track_head launches so far (the flag word holds the last finished one's number)
     std::string last_error;
 };
+// behind the counters, the statistics staging (256 B) and the pose step's ticket (256 B): 256 B for the head words
+inline unsigned long long* vo_int_head_words(vo_ctx* ctx) {
+    return reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->d_counters) + VO_COUNTER_SHARDS * 4 * sizeof(unsigned long long) + 512);
+}
 
 #define VO_HIP_CHECK(ctx, expr)                                                        \
     do {                                                                               \
@@ -88,7 +94,11 @@ int vo_launch_frame_build(vo_ctx* ctx, vo_pyr* f, const uint8_t* d_img, hipStrea
 int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d_pu, const double* d_pv, int n,
                   int wu, int wv, int max_iters, double eps, double max_bidir, double* d_qu, double* d_qv,
                   uint8_t* d_valid, float* d_score, float* d_fb,
-                  const int32_t* d_n = nullptr);   // d_n: the keypoint count on the device, n its upper bound
+                  const int32_t* d_n = nullptr,    // d_n: the keypoint count on the device, n its upper bound
+                  int n_head = 0);                 // > 0: the first n_head keypoints are a head (vo_dev_klt_track_head)
+int vo_launch_wait_head(vo_ctx* ctx);              // ctx->stream waits (a polling kernel) for the last head launched
+// three words of the ctx for the head of a tracking launch: arrival count, flag (epoch of the last finished head), time-out
+// (vo_int_head_words, above)
 
 struct vo_sel_work {       // device scratch of the selection pipeline
     double* resp; unsigned long long* maxbits; int32_t* blk_counts; int32_t* blk_offs;

@@ -39,6 +39,10 @@ struct LKArgs {
     float *score, *fb;
     unsigned long long* counters; // VO_COUNTER_SHARDS x 4
     const int32_t* n_dev;         // optional: the launch covers an upper bound n, the number of keypoints is *n_dev on the device
+    // head of the launch (vo_dev_klt_track_head): the first n_head keypoints are a set of their own whose consumers start
+    // when the last of them is done, while the rest of the launch is still running.  head_cnt counts finished head
+    // keypoints (zero between launches: the last arriver sets it back), head_flag receives head_epoch from the last arriver.
+    int n_head; unsigned head_epoch; unsigned* head_cnt; unsigned* head_flag;
 };
 
 template <int BW_, int BH_, int LU_, int LV_, int PW_, bool COL_, int WAVES_>
@@ -170,10 +174,14 @@ __device__ __forceinline__ void level_dims(int nu0, int nv0, int l, int& nu, int
 typedef __attribute__((address_space(3))) float lds_float;
 typedef __attribute__((address_space(1))) const float glb_float;
 
+// stage_issue starts the transfers (the patch must not be read, and not be waited for twice, until stage_wait has
+// run); stage = the two together.  Split so that the first search patch of a level can travel while the level's
+// template sums and 2x2 system are being finished (lk_dir).
 template <class C>
-__device__ __forceinline__ void stage(float* patch, const float* __restrict__ img, int pitch, int nu, int nv, int ou, int ov,
-                                      int lane, int lr, int lq) {
+__device__ __forceinline__ void stage_issue(float* patch, const float* __restrict__ img, int pitch, int nu, int nv, int ou, int ov,
+                                            int lane, int lr, int lq) {
 #if defined(__HIP_DEVICE_COMPILE__) // the host pass cannot type-check the 16-byte LDS-DMA builtin
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a patch sent ahead that nobody waited for (flat level) has landed
     __syncthreads();
     lds_float* lp = reinterpret_cast<lds_float*>(reinterpret_cast<uintptr_t>(patch));
     // A caller's keypoint may be anything (infinite, 1e12: the float -> int conversion saturates and the
@@ -214,9 +222,19 @@ __device__ __forceinline__ void stage(float* patch, const float* __restrict__ im
             }
         }
     }
+#endif
+}
+__device__ __forceinline__ void stage_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #endif
+}
+template <class C>
+__device__ __forceinline__ void stage(float* patch, const float* __restrict__ img, int pitch, int nu, int nv, int ou, int ov,
+                                      int lane, int lr, int lq) {
+    stage_issue<C>(patch, img, pitch, nu, nv, ou, ov, lane, lr, lq);
+    stage_wait();
 }
 
 __device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
@@ -250,6 +268,14 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
         level_dims(nu0, nv0, l, nu, nv, lo, pitch);
         const double plu = ldexp(su, -l), plv = ldexp(sv, -l); // = su / 2^l, exact
         float sxx = 0, sxy = 0, syy = 0, ctu = 0, ctv = 0;
+        // where the iteration of this level starts: position = (ibu + fbu + du, ibv + fbv + dv), integer base + float
+        // remainder.  Known before the set-up, so the first search patch is sent for as soon as the template's samples
+        // have left the LDS, and travels while the sums and the 2x2 system are being finished.
+        const double bu0 = plu + gu, bv0 = plv + gv;
+        const double fbu0 = floor(bu0), fbv0 = floor(bv0);
+        const int ibu = uni((int)fbu0), ibv = uni((int)fbv0);
+        const float fbu = unif((float)(bu0 - fbu0)), fbv = unif((float)(bv0 - fbv0));
+        int pou = ibu - ru - LK_M, pov = ibv - rv - LK_M;
         {   // ---- template set-up: E = samples on the window grown by one pixel, Sobel/8 of E.
             // Rows stream through a 3-row ring so that only 3 x (BW+2) samples are live at a time.
             const double flu = floor(plu), flv = floor(plv);
@@ -323,6 +349,14 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                 }
             }
             ++setups;
+            // every lane has its template samples in registers: the LDS is free for the search patch (a start far
+            // outside the image goes through the clamped form inside; the lost test of the first iteration still
+            // comes before anything is read from it)
+            // (the five sums are pinned in front of the transfers -- an empty volatile asm that reads them: left free, the
+            // compiler hoisted all of the rows' LDS reads in front of the transfers' barrier and sank their arithmetic
+            // behind it, 54 samples live at once, and the set-up ran 2 % longer)
+            asm volatile("" :: "v"(sxx), "v"(sxy), "v"(syy), "v"(ctu), "v"(ctv));
+            stage_issue<C>(patch, B + lo, pitch, nu, nv, pou, pov, lane, lr, lq);
         }
         // sums of the x8 gradients: S = 64 G
         float s5in[5] = {sxx, sxy, syy, ctu, ctv}, s5[5];
@@ -350,18 +384,13 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             rdet = rdet * fmaf(-detS, rdet, 2.0f);
             const float r8 = 8.0f * rdet;
             const float iuu = unif(s5[2] * r8), iuv = unif(-s5[1] * r8), ivv = unif(s5[0] * r8);
-            // position = (ibu + fbu + du, ibv + fbv + dv): integer base + float remainder
-            const double bu0 = plu + gu, bv0 = plv + gv;
-            const double fbu0 = floor(bu0), fbv0 = floor(bv0);
-            const int ibu = uni((int)fbu0), ibv = uni((int)fbv0);
-            const float fbu = unif((float)(bu0 - fbu0)), fbv = unif((float)(bv0 - fbv0));
             // N4 lost test, (ibu + tu) 2^l inside [0, nu0 - 1], as bounds on tu itself (2^l is a power of two and the base
             // an integer: the bounds are exact)
             const float isf = __builtin_ldexpf(1.0f, -l);
             const float tlo_u = -(float)ibu, thi_u = (float)(nu0 - 1) * isf - (float)ibu;
             const float tlo_v = -(float)ibv, thi_v = (float)(nv0 - 1) * isf - (float)ibv;
-            bool staged = false, cell = false;
-            int pou = 0, pov = 0, ciu = 0, civ = 0;
+            bool staged = true, landed = false, cell = false;   // the patch sent for above: staged, not waited for yet
+            int ciu = 0, civ = 0;
             // sum J*(Tu,Tv) is bilinear in the sub-pixel fractions: inside one pixel cell it is the
             // interpolation of the four integer-offset correlations c[dv][du] = sum P(x+du, y+dv)*(Tu,Tv).
             // They are computed once per visited cell; an iteration inside the cell is scalar work.
@@ -369,20 +398,21 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             float ku0 = 0, kua = 0, kub = 0, kuc = 0, kv0 = 0, kva = 0, kvb = 0, kvc = 0;
             for (int it = 0; it < a.max_iters; ++it) {
                 const float tu = fbu + du, tv = fbv + dv;
-                if (__builtin_amdgcn_ballot_w64(!(tu >= tlo_u && tu <= thi_u && tv >= tlo_v && tv <= thi_v))) {
+                // (bitwise &: the four compares feed one scalar mask, no branch between them)
+                if (__builtin_amdgcn_ballot_w64(!((tu >= tlo_u) & (tu <= thi_u) & (tv >= tlo_v) & (tv <= thi_v)))) {
                     flags |= 1;
                     break;
                 }
-                const float flu = floorf(tu), flv = floorf(tv);
-                const int iu = ibu + uni((int)flu), iv = ibv + uni((int)flv);
+                const int iu = ibu + uni((int)floorf(tu)), iv = ibv + uni((int)floorf(tv));
                 if (!cell || iu != ciu || iv != civ) {
                     int fi = iu - ru - pou, fj = iv - rv - pov;
                     if (!staged || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) {
                         pou = iu - ru - LK_M; pov = iv - rv - LK_M;
                         stage<C>(patch, B + lo, pitch, nu, nv, pou, pov, lane, lr, lq);
-                        staged = true;
+                        staged = true; landed = true;
                         fi = LK_M; fj = LK_M;
                     }
+                    if (!landed) { stage_wait(); landed = true; }
                     const int base = lbase + fj * PW + fi;
                     float su00 = 0, su10 = 0, su01 = 0, su11 = 0, sv00 = 0, sv10 = 0, sv01 = 0, sv11 = 0;
 #pragma unroll
@@ -414,7 +444,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
                     cell = true; ciu = iu; civ = iv;
                     ++cells;
                 }
-                const float fu = tu - flu, fv = tv - flv;
+                const float fu = __builtin_amdgcn_fractf(tu), fv = __builtin_amdgcn_fractf(tv);   // = tu - floor(tu)
                 const float Bu = (ku0 - fu * kua) - fv * (kub + fu * kuc);
                 const float Bv = (kv0 - fu * kva) - fv * (kvb + fu * kvc);
                 ++iters;
@@ -429,6 +459,9 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
         if (l > 0) { gu = 2.0 * (gu + (double)du); gv = 2.0 * (gv + (double)dv); }
         else { gu = gu + (double)du; gv = gv + (double)dv; }
     }
+    // a search patch sent ahead that nothing waited for (a flat level, a point lost at its first iteration) must have
+    // landed before the LDS is used again -- by this wave, or by the workgroup that gets the LDS after this one ends
+    stage_wait();
     qu = su + gu; qv = sv + gv;
     if (!(flags & 1)) {
         if (!(qu >= 0.0 && qu <= (double)(nu0 - 1) && qv >= 0.0 && qv <= (double)(nv0 - 1))) flags |= 1;
@@ -547,8 +580,26 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
         }
     }
     if (lane == 0) {
-        a.qu[kp] = fu; a.qv[kp] = fv;
-        a.valid[kp] = ok ? 1 : 0;
+        if (kp < a.n_head) {
+            // A head keypoint: its results are read by kernels that start while this launch is still running (other
+            // CUs, other XCDs, no kernel boundary behind this launch yet).  Write-through stores at agent scope, drained,
+            // then the arrival count (MI355X_MICROARCH.md, "Valid forms": every store sc1, every storing wave's vmcnt(0)
+            // before its add; the readers are later kernels and acquire at their own start).
+            __hip_atomic_store(&a.qu[kp], fu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.qv[kp], fv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.valid[kp], (uint8_t)(ok ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned before = __hip_atomic_fetch_add(a.head_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned n_head = a.n_dev ? (unsigned)min(a.n_head, *a.n_dev) : (unsigned)a.n_head;
+            if (before + 1u == n_head) {
+                __hip_atomic_store(a.head_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(a.head_flag, a.head_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            a.qu[kp] = fu; a.qv[kp] = fv;
+            a.valid[kp] = ok ? 1 : 0;
+        }
         if constexpr (SCORE) {
             float sc = 0.0f;
             if (!(fl & 1)) {
@@ -568,6 +619,19 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
     }
 }
 
+// The consumers' side of a head (vo_dev_wait_head): one lane polls the flag until the launch's epoch is there.  Bounded:
+// after ~0.25 s of polling it gives up and raises *timed_out (the launch it waits for was never enqueued, or sits behind
+// this kernel in the same hardware queue) -- every wave of this kernel reaches its end whatever happens.
+__global__ __launch_bounds__(64) void k_wait_head(const unsigned* flag, unsigned epoch, unsigned* timed_out) {
+    if (threadIdx.x != 0) return;
+    for (int spin = 0; spin < 250000; ++spin) {
+        const unsigned f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(f - epoch) >= 0) return;
+        __builtin_amdgcn_s_sleep(32);   // ~2k cycles: the poll costs the memory system nothing
+    }
+    __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <class C, bool SCORE>
 void launch_s(const LKArgs& a, hipStream_t st) {
     // the window that cuts only the last column / row of blocks the way WinMask<true> assumes
@@ -582,9 +646,16 @@ void launch(const LKArgs& a, hipStream_t st) {
 
 } // namespace
 
+int vo_launch_wait_head(vo_ctx* ctx) {
+    unsigned* w = reinterpret_cast<unsigned*>(vo_int_head_words(ctx));
+    hipLaunchKernelGGL(k_wait_head, dim3(1), dim3(64), 0, ctx->stream, w + 1, ctx->head_epoch, w + 2);
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}
+
 int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d_pu, const double* d_pv, int n,
                   int wu, int wv, int max_iters, double eps, double max_bidir, double* d_qu, double* d_qv,
-                  uint8_t* d_valid, float* d_score, float* d_fb, const int32_t* d_n) {
+                  uint8_t* d_valid, float* d_score, float* d_fb, const int32_t* d_n, int n_head) {
     if (n <= 0) return VO_OK;
     if (!(wu & 1) || !(wv & 1) || wu < 3 || wv < 3 || max_iters < 1) { ctx->last_error = "klt: BlockSize must be odd >= 3, MaxIterations >= 1"; return VO_ERR_BAD_ARG; }
     if (A->nu != B->nu || A->nv != B->nv || A->levels != B->levels) { ctx->last_error = "klt: frame shapes differ"; return VO_ERR_BAD_ARG; }
@@ -597,6 +668,11 @@ int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d
     a.flat_thr = 64.0 * 2.0 * (double)a.npx * (double)VO_MIN_EIG;
     a.pu = d_pu; a.pv = d_pv; a.qu = d_qu; a.qv = d_qv; a.valid = d_valid; a.score = d_score; a.fb = d_fb;
     a.counters = ctx->d_counters; a.n_dev = d_n;
+    a.n_head = 0; a.head_epoch = 0; a.head_cnt = a.head_flag = nullptr;
+    if (n_head > 0) {
+        unsigned* w = reinterpret_cast<unsigned*>(vo_int_head_words(ctx));
+        a.n_head = n_head < n ? n_head : n; a.head_epoch = ++ctx->head_epoch; a.head_cnt = w; a.head_flag = w + 1;
+    }
     if (wu <= CfgS::MAXU && wv <= CfgS::MAXV) launch<CfgS>(a, ctx->stream);
     else if (wu <= CfgM::MAXU && wv <= CfgM::MAXV) launch<CfgM>(a, ctx->stream);
     else if (wu <= CfgL::MAXU && wv <= CfgL::MAXV) launch<CfgL>(a, ctx->stream);

@@ -23,7 +23,7 @@ def _p(t):
 class FrameWorkload:
     def __init__(self, ctx, n_landmarks, n_candidates, nv=376, nu=1241, n_frames=16, num_hyp=2000, levels=4,
                  block=41, max_iters=50, eps=0.01, max_bidir=2.0, keep=100, seed=1023, device=None, ahead=None,
-                 lane_priority=False):
+                 lane_priority=False, head=None):
         """ahead: the image-only work of a frame (pyramid, corner detection) is issued one step ahead on the side
         stream (vo_dev_frame_prefetch); None: on unless VO_NO_PREFETCH is set (A/B switch for profiling)."""
         self.ctx = ctx
@@ -33,6 +33,11 @@ class FrameWorkload:
         # tracking of :71 neither).  VO_NO_LANE=1: one tracking launch over both sets, then the pose (A/B switch).
         self.lane = not os.environ.get("VO_NO_LANE")
         self.scores = bool(os.environ.get("VO_KLT_SCORES"))      # the frame step discards the tracker's scores
+        # head schedule (default): both point sets in ONE tracking launch with the landmarks as its head -- dispatched
+        # first, the pose chain on the lane released by the last of them (vo_dev_klt_track_head / vo_dev_wait_head): the
+        # order of the blocks does what the stream priority did, at any priority.  VO_NO_HEAD=1: two launches on two
+        # streams (round 2's form, which needs the high-priority lane to start the pose chain early).
+        self.head = (not os.environ.get("VO_NO_HEAD")) if head is None else bool(head)
         # lane_priority: the lane as a high-priority stream (vo_ctx_lane_priority) -- for a process with one ctx on a GPU of
         # its own (bench.py); refused, and ignored here, once the ctx's lane exists
         if lane_priority and self.lane:
@@ -110,6 +115,12 @@ class FrameWorkload:
     def track_all(self, a, b):
         self.track(a, b, self.pa, self.qa, self.va, self.sa if self.scores else None)
 
+    def track_head(self, a, b):
+        """landmarks + candidates in one launch, the landmarks as its head"""
+        self.ctx.call("vo_dev_klt_track_head", a, b, _p(self.pa[0]), _p(self.pa[1]), self.nl, self.nl + self.nc, self.block,
+                      self.block, self.max_iters, C.c_double(self.eps), C.c_double(self.max_bidir), _p(self.qa[0]), _p(self.qa[1]),
+                      _p(self.va), _p(self.sa if self.scores else None), None)
+
     def track_landmarks(self, a, b):
         self.track(a, b, self.pl, self.ql, self.vl, self.sl if self.scores else None)
 
@@ -151,7 +162,16 @@ class FrameWorkload:
         a = 3 if k % n == 0 else (k - 1) % 3
         b = k % 3
         branch = self.lane and not lap and self.nl >= 4
-        if branch:
+        if branch and self.head:
+            self.ctx.call("vo_dev_frame_wait", a); self.ctx.call("vo_dev_frame_wait", b)
+            self.ctx.call("vo_ctx_lane_begin")   # the lane forks HERE, in front of the tracking launch ...
+            self.ctx.call("vo_ctx_lane_end")
+            self.track_head(a, b)                # ... which is enqueued before the kernel that waits for its head
+            self.ctx.call("vo_ctx_lane_resume")
+            self.ctx.call("vo_dev_wait_head")
+            self.pose()
+            self.ctx.call("vo_ctx_lane_end")
+        elif branch:
             self.ctx.call("vo_dev_frame_wait", a); self.ctx.call("vo_dev_frame_wait", b)
             self.ctx.call("vo_ctx_lane_begin")
             self.track_landmarks(a, b)
