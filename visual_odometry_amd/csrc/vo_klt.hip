@@ -252,7 +252,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     float Tu[BH][BW], Tv[BH][BW];
     const int ru = (a.wu - 1) / 2, rv = (a.wv - 1) / 2;
     const int nu0 = a.nu0, nv0 = a.nv0;
-    double gu = 0, gv = 0;
+    float gu = 0, gv = 0;   // displacement carried from level to level: tens of pixels at most, fp32 keeps 1e-6 px of it
     int flags = 0;
     // A start that is not finite or is absurdly far away is lost before anything is staged: every path below
     // would end there too (flat at every level or the first lost test, displacement 0), and from here on all
@@ -263,24 +263,31 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     }
     bool staged0 = false; // level 0: is a B patch staged, and where (re-used by the score)
     int pou0 = 0, pov0 = 0;
+    // The start as integer pixel + fraction: a level's position su / 2^l is then a shift and a mask on the integer and one
+    // fp32 scaling of the remainder, and the per-level position arithmetic needs no fp64 (eight levels x directions of ~20
+    // double-rate instructions on wave-uniform values; the fraction's rounding is below 3e-7 px).
+    const double fsu_d = floor(su), fsv_d = floor(sv);
+    const int isu = uni((int)fsu_d), isv = uni((int)fsv_d);
+    const float fsu = unif((float)(su - fsu_d)), fsv = unif((float)(sv - fsv_d));
     for (int l = a.levels - 1; l >= 0; --l) {
         int nu, nv, pitch; long lo;
         level_dims(nu0, nv0, l, nu, nv, lo, pitch);
-        const double plu = ldexp(su, -l), plv = ldexp(sv, -l); // = su / 2^l, exact
+        const int lmask = (1 << l) - 1;
+        const int iplu = isu >> l, iplv = isv >> l;                      // floor(su / 2^l), negative starts included
+        const float fplu = unif(__builtin_ldexpf((float)(isu & lmask) + fsu, -l));
+        const float fplv = unif(__builtin_ldexpf((float)(isv & lmask) + fsv, -l));
         float sxx = 0, sxy = 0, syy = 0, ctu = 0, ctv = 0;
         // where the iteration of this level starts: position = (ibu + fbu + du, ibv + fbv + dv), integer base + float
         // remainder.  Known before the set-up, so the first search patch is sent for as soon as the template's samples
         // have left the LDS, and travels while the sums and the 2x2 system are being finished.
-        const double bu0 = plu + gu, bv0 = plv + gv;
-        const double fbu0 = floor(bu0), fbv0 = floor(bv0);
-        const int ibu = uni((int)fbu0), ibv = uni((int)fbv0);
-        const float fbu = unif((float)(bu0 - fbu0)), fbv = unif((float)(bv0 - fbv0));
+        const float bu0 = fplu + gu, bv0 = fplv + gv;
+        const int ibu = iplu + uni((int)floorf(bu0)), ibv = iplv + uni((int)floorf(bv0));
+        const float fbu = unif(__builtin_amdgcn_fractf(bu0)), fbv = unif(__builtin_amdgcn_fractf(bv0));
         int pou = ibu - ru - LK_M, pov = ibv - rv - LK_M;
         {   // ---- template set-up: E = samples on the window grown by one pixel, Sobel/8 of E.
             // Rows stream through a 3-row ring so that only 3 x (BW+2) samples are live at a time.
-            const double flu = floor(plu), flv = floor(plv);
-            const float fu = unif((float)(plu - flu)), fv = unif((float)(plv - flv));
-            stage<C>(patch, A + lo, pitch, nu, nv, uni((int)flu) - ru - 1, uni((int)flv) - rv - 1, lane, lr, lq);
+            const float fu = fplu, fv = fplv;
+            stage<C>(patch, A + lo, pitch, nu, nv, iplu - ru - 1, iplv - rv - 1, lane, lr, lq);
             // E rows stream through a 3-row ring.  Separable Sobel per template row: VD = vertical
             // difference, VS = vertical 1-2-1 smoothing of the three rows, then the horizontal halves.
             // Gradients are kept times 8 (the 1/8 of the operator is a power of two: it is folded,
@@ -456,13 +463,13 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             if (l == 0) { staged0 = staged; pou0 = pou; pov0 = pov; }
         }
         if (flags & 1) break;
-        if (l > 0) { gu = 2.0 * (gu + (double)du); gv = 2.0 * (gv + (double)dv); }
-        else { gu = gu + (double)du; gv = gv + (double)dv; }
+        if (l > 0) { gu = 2.0f * (gu + du); gv = 2.0f * (gv + dv); }
+        else { gu = gu + du; gv = gv + dv; }
     }
     // a search patch sent ahead that nothing waited for (a flat level, a point lost at its first iteration) must have
     // landed before the LDS is used again -- by this wave, or by the workgroup that gets the LDS after this one ends
     stage_wait();
-    qu = su + gu; qv = sv + gv;
+    qu = su + (double)gu; qv = sv + (double)gv;
     if (!(flags & 1)) {
         if (!(qu >= 0.0 && qu <= (double)(nu0 - 1) && qv >= 0.0 && qv <= (double)(nv0 - 1))) flags |= 1;
     }
