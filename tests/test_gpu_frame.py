@@ -177,6 +177,45 @@ def test_merge_beyond_the_lds_copies(ctx, sequence):
         loop.close()
 
 
+def test_merge_at_the_stress_size(ctx):
+    """BASELINE configs[3]'s sizes through the device-resident loop: a KITTI-shaped frame, 25 000 landmarks at the cap
+    (maxNumLandmarks = 25 000) and ~7 000 candidates of which more than 5 000 are promotable -- the first fill the places
+    of the landmarks that failed to track, every later one replaces the worst landmark if its own error is not larger
+    (modules/VisualOdometry.m:87-142: max-before-edit :89-90, replace-worst :116-122, append :123-127, ageing :130-139).
+    Through the sort-based merge (k_sort_*), against the oracle's sequential walk: same accepted and surviving sets in
+    the same order."""
+    KK = synth.KITTI_K
+    frames, poses, lift = synth.plane_sequence(10, KK, nv=376, nu=1241, depth=20.0, step=(0.2, 0.0, 0.15))
+    k = 8
+    rng = np.random.default_rng(11)
+
+    def lift_at(pose, u, v, depth=20.0):
+        R, C = pose[:3], pose[3]
+        d = R.T @ (np.linalg.inv(KK) @ np.stack([u, v, np.ones_like(u)]))
+        lam = (depth - C[2]) / d[2]
+        return (C[:, None] + lam * d).T
+    n_l, n_c = 25000, 7000
+    st = vo_frame.new_state()
+    lu = rng.uniform(25, 1241 - 26, n_l); lv = rng.uniform(25, 376 - 26, n_l)
+    st.keypoints = np.stack([lu, lv], 1); st.landmarks = lift_at(poses[k - 1], lu, lv); st.reproError = np.zeros(n_l)
+    u0 = rng.uniform(30, 1241 - 31, n_c); v0 = rng.uniform(30, 376 - 31, n_c)
+    X = lift(u0, v0)
+    uv, z = synth.project(KK, poses[k - 1][:3], poses[k - 1][3], X)
+    ok = (uv[:, 0] > 25) & (uv[:, 0] < 1241 - 26) & (uv[:, 1] > 25) & (uv[:, 1] < 376 - 26)
+    st.candidate_keypoints = uv[ok]; st.candidate_first_keypoints = np.stack([u0, v0], 1)[ok]
+    st.candidate_first_poses = np.repeat(poses[0][None], ok.sum(), 0)
+    st.candidate_time_indxs = -np.full(ok.sum(), k - 1, np.int64)
+    assert ok.sum() > 6000
+    loop = FrameLoop(KK, frames[0].shape, maxNumLandmarks=n_l, maxCandidates=8000, CandidatesToKeep=100, ctx=ctx)
+    loop.set_state(st, frames[k - 1], frame_no=k - 1)
+    gpose, gstatus, ginfo = loop.processFrame(frames[k])
+    o, pose, status, info = vo_frame.process_frame(frames[k - 1], frames[k], st, KK, k, maxNumLandmarks=n_l, threads=16)
+    assert gstatus == status == 0
+    assert ginfo["n_promoted"] == info["promoted"] > 5000 and info["replaced"] > 3000 and ginfo["n_landmarks"] == n_l
+    assert_states_match(loop.get_state(), o)
+    loop.close()
+
+
 def synth_lift_at(pose, u, v, depth=12.0):
     """landmarks on the plane Z = depth seen at pixel (u, v) from `pose` ([R_cw; C])"""
     R, C = pose[:3], pose[3]

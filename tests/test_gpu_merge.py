@@ -1,0 +1,72 @@
+"""The sort-based merge (vo_dev_merge_ranks; what the device-resident frame loop runs for large pools, csrc/vo_frame.hip)
+against the SEQUENTIAL policy of modules/VisualOdometry.m:87-142 walked candidate by candidate on the host (a heap holds
+the landmark set: the first maximum is the largest error, earliest in the list among equals) -- accepted and surviving
+sets entry by entry, on tie-heavy random pools from a handful of entries to 60 000 (several sort tiles, partner runs
+shorter than their neighbours, the cap reached early, late and never)."""
+import ctypes as C
+import heapq
+
+import numpy as np
+import pytest
+
+from visual_odometry_amd._lib import ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def sequential(init, cand, cap):
+    """-> (survives over the pool [init; cand], accepted over cand).  :89-90 the maximum before the edit, :116-122
+    replace the first maximum if the candidate's error is not larger, :123-127 append below the cap."""
+    n0 = len(init)
+    heap = [(-v, i) for i, v in enumerate(init)]            # max-heap on the error; among equals the earliest entry
+    heapq.heapify(heap)
+    alive = np.zeros(n0 + len(cand), bool); alive[:n0] = True
+    acc = np.zeros(len(cand), bool)
+    size = n0
+    for j, r in enumerate(cand):
+        if size >= cap and size > 0 and r <= -heap[0][0]:
+            _, gone = heapq.heappop(heap)
+            alive[gone] = False; size -= 1
+        if size < cap:
+            heapq.heappush(heap, (-r, n0 + j)); alive[n0 + j] = True; acc[j] = True; size += 1
+    return alive, acc
+
+
+def device(ctx, torch, init, cand, cap):
+    pool = torch.from_numpy(np.concatenate([init, cand]).astype(np.float64)).cuda()
+    surv = torch.full((len(pool),), 9, dtype=torch.uint8, device="cuda"); acc = torch.full_like(surv, 9)
+    ctx.call("vo_dev_merge_ranks", ptr(pool), len(init), len(cand), int(cap), ptr(surv), ptr(acc))
+    ctx.sync()
+    return surv.cpu().numpy().astype(bool), acc.cpu().numpy().astype(bool)[len(init):]
+
+
+@pytest.mark.parametrize("n0,n_c,cap,levels", [
+    (0, 1, 1, 2), (3, 0, 5, 2), (5, 9, 5, 3), (12, 40, 12, 4), (100, 300, 150, 5), (2047, 1, 2047, 7), (2048, 1, 2048, 3),
+    (1500, 600, 1500, 6), (2000, 2100, 2048, 9), (4000, 2500, 5000, 11), (25000, 6000, 25000, 50), (25000, 6000, 25000, 100000),
+    (20000, 30000, 25000, 17), (300, 59000, 40000, 5), (30000, 30000, 100, 12), (6000, 100, 0, 3)])
+def test_sorted_merge_equals_the_sequential_policy(ctx, n0, n_c, cap, levels):
+    import torch
+    rng = np.random.default_rng(n0 * 7 + n_c + cap)
+    init = rng.integers(0, levels, n0) / 4.0                 # tie-heavy: a few distinct errors
+    cand = rng.integers(0, levels, n_c) / 4.0
+    if cap and n0 > cap:
+        init = init[:cap]; n0 = cap
+    want_s, want_a = sequential(init, cand, cap)
+    got_s, got_a = device(ctx, torch, init, cand, cap)
+    if cap == 0:                                             # nothing fits: nothing is accepted, the list stays as it is
+        assert not got_a.any()
+        return
+    assert np.array_equal(got_a, want_a), (n0, n_c, cap, int((got_a != want_a).sum()))
+    # an accepted candidate that was evicted later is not a survivor; a rejected one never was
+    assert np.array_equal(got_s[:n0], want_s[:n0]) and np.array_equal(got_s[n0:] & got_a, want_s[n0:])
+
+
+def test_continuous_errors_and_the_frame_loops_sizes(ctx):
+    """distinct errors (the usual case), pool of 25k landmarks at the cap + 25k candidates"""
+    import torch
+    rng = np.random.default_rng(3)
+    init = rng.uniform(0, 3, 25000); cand = rng.uniform(0, 3, 25000)
+    want_s, want_a = sequential(init, cand, 25000)
+    got_s, got_a = device(ctx, torch, init, cand, 25000)
+    assert np.array_equal(got_a, want_a) and np.array_equal(got_s[:25000], want_s[:25000])
+    assert np.array_equal(got_s[25000:] & got_a, want_s[25000:]) and 5000 < want_a.sum() < 25000

@@ -165,3 +165,58 @@ def test_merge_policy_closed_form_equals_the_sequential_loop():
         cap = int(rng.integers(1, 14)); n0 = min(int(rng.integers(0, 12)), cap); q = int(rng.integers(1, 6))
         init = rng.integers(0, q, n0) / 2.0; cand = rng.integers(0, q, int(rng.integers(0, 15))) / 2.0
         assert sequential(init, cand, cap) == closed(init, cand, cap)
+
+
+def test_sort_based_merge_equals_the_sequential_loop_on_tie_heavy_pools():
+    """The device merge for LARGE pools (round 3: k_sort_tiles / k_sort_merge / k_sort_ranks, vo_frame.hip) takes both
+    decisions from one stable merge sort by reproError: `before` = the strictly smaller keys of the left-hand runs an
+    entry is merged with, level by level; `rank` = the sorted position mirrored inside its group of equal keys.  The
+    same steps in numpy (same run structure, same binary searches, a padded tail of +inf keys, partner runs shorter
+    than their neighbours) against the sequential policy of modules/VisualOdometry.m:87-127, on pools with many ties.
+    tests/test_gpu_merge.py holds the kernels themselves to the same policy up to 60 000 entries."""
+    rng = np.random.default_rng(1)
+
+    def sequential(init, cand, cap):
+        vals = list(init); ids = list(range(len(init))); acc = np.zeros(len(cand), bool)
+        for j, r in enumerate(cand):
+            mi, mx = (int(np.argmax(vals)), max(vals)) if vals else (-1, -np.inf)       # :89-90
+            if len(vals) >= cap and r <= mx:                                            # :116-122
+                del vals[mi]; del ids[mi]
+            if len(vals) < cap:                                                         # :123-127
+                vals.append(r); ids.append(len(init) + j); acc[j] = True
+        surv = np.zeros(len(init) + len(cand), bool); surv[ids] = True
+        return surv, acc
+
+    def by_sort(init, cand, cap, tile):
+        pool = np.concatenate([init, cand]).astype(float); P = len(pool)
+        padded = (P + tile - 1) // tile * tile
+        key = np.full(padded, np.inf); key[:P] = pool; idx = np.arange(padded); before = np.zeros(padded, int)
+        L = 1
+        while L < padded:
+            nk, ni = key.copy(), idx.copy()
+            for p in range(padded):
+                run = p // L; base = (run >> 1) * 2 * L; v = key[p]
+                if base + L >= padded:
+                    d, sm = p, 0                                   # a last run without a partner moves as it is
+                elif run & 1:                                      # right-hand run: behind the left keys <= v
+                    le = np.searchsorted(key[base:base + L], v, "right")
+                    sm = np.searchsorted(key[base:base + le], v, "left")
+                    d = base + (p - (base + L)) + le
+                else:                                              # left-hand run: behind the right keys < v
+                    sm = 0
+                    d = base + (p - base) + np.searchsorted(key[base + L:min(base + 2 * L, padded)], v, "left")
+                nk[d] = v; ni[d] = idx[p]; before[idx[p]] += sm
+            key, idx = nk, ni; L *= 2
+        surv = np.zeros(P, bool); acc = np.zeros(P, bool)
+        for p in range(P):
+            lo = np.searchsorted(key[:P], key[p], "left"); hi = np.searchsorted(key[:P], key[p], "right")
+            surv[idx[p]] = lo + (hi - 1 - p) < cap
+            acc[idx[p]] = before[idx[p]] < cap
+        return surv, acc[len(init):]
+    for _ in range(300):
+        cap = int(rng.integers(1, 30)); n0 = min(int(rng.integers(0, 28)), cap); q = int(rng.integers(1, 6))
+        init = rng.integers(0, q, n0) / 2.0; cand = rng.integers(0, q, int(rng.integers(0, 40))) / 2.0
+        ws, wa = sequential(init, cand, cap)
+        gs, ga = by_sort(init, cand, cap, tile=int(rng.choice([1, 4, 8, 16])))
+        assert np.array_equal(ga, wa)
+        assert np.array_equal(gs[:n0], ws[:n0]) and np.array_equal(gs[n0:] & ga, ws[n0:])

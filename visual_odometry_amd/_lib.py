@@ -68,7 +68,7 @@ EXPORTS = [
     "vo_select_keypoints_greedy", "vo_triangulate_candidates", "vo_angle_deg", "vo_in_front", "vo_reproj_error",
     "vo_p3p_ransac", "vo_p3p_batch", "vo_essential_ransac", "vo_dev_frame_build", "vo_dev_klt_track", "vo_dev_klt_track_head", "vo_dev_wait_head", "vo_dev_head_timed_out", "vo_dev_select_candidates", "vo_dev_select_begin", "vo_dev_select_finish",
     "vo_dev_frame_prefetch",
-    "vo_dev_triangulate", "vo_dev_p3p_ransac", "vo_dev_p3p_ransac_static", "vo_frame_create", "vo_frame_destroy", "vo_frame_set_state",
+    "vo_dev_triangulate", "vo_dev_p3p_ransac", "vo_dev_p3p_ransac_static", "vo_dev_merge_ranks", "vo_frame_create", "vo_frame_destroy", "vo_frame_set_state",
     "vo_frame_get_counts", "vo_frame_get_state", "vo_frame_set_image", "vo_frame_process", "vo_frame_submit", "vo_frame_collect", "vo_frame_announce",
     "vo_image_info", "vo_image_decode", "vo_rgb2gray", "vo_ingest_open", "vo_ingest_count", "vo_ingest_next",
     "vo_ingest_read", "vo_ingest_stats", "vo_ingest_set_hold", "vo_ingest_close",

@@ -300,10 +300,20 @@ __global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a, CandOp cop, int
     if (tid == 0) sizes[0] = *count_l < a.cap ? *count_l : a.cap;
 }
 
-// The same in three launches for pools beyond a few hundred entries, where one block walking all pairs is too
-// slow: the list and the pool (one block), the two counts with 16 lanes per element over the whole chip, the
-// ordered write (one block).  pool: PW doubles; surv / acc: PW bytes each; np_out: one int.
-struct MergeWideArgs { MergeArgs m; double* pool; uint8_t *surv, *acc; int32_t* np_out; };
+// The same for pools beyond a few hundred entries, where one block walking all pairs is too slow -- and without the
+// all-pairs walk at all (round 3; the first wide form spread the O(pool^2) counts over the chip): both counts come out
+// of ONE stable merge sort of the pool by reproError, O(n log n):
+//   before(e) = #{x earlier in order : v_x < v_e}: in a bottom-up merge sort over the pool in order, the elements earlier
+//               than e are exactly the left-hand runs e's run is merged with, level by level; e's rank among the
+//               strictly smaller keys of that left run (a binary search the merge needs anyway) is that level's share;
+//   rank(e)   = #{x : v_x < v_e} + #{x : v_x = v_e, x later}: e's place in the sorted sequence with the ties of equal
+//               keys reversed -- its sorted position mirrored inside its group of equal keys.
+// Launches: the list and the pool (one block), runs of SORT_TILE elements sorted in LDS (one block per run), one launch
+// per remaining doubling of the run length, the ranks, the ordered write (one block).  Keys beyond the pool are +inf
+// (never below or equal to a real key: reproError is finite wherever the classes let a candidate in).
+// pool: the keys in pool order; key / idx: two buffers each of the padded length; before: one int per pool entry.
+struct MergeWideArgs { MergeArgs m; double* pool; uint8_t *surv, *acc; int32_t* np_out; double* key[2]; int32_t* idx[2]; int32_t* before; int padded; };
+constexpr int SORT_TILE = 2048;     // elements sorted by one block in LDS (8 per thread)
 
 __global__ __launch_bounds__(1024) void k_merge_list(MergeWideArgs w) {
     __shared__ int s_w[16];
@@ -323,33 +333,101 @@ __global__ __launch_bounds__(1024) void k_merge_list(MergeWideArgs w) {
     if (tid == 0) *w.np_out = np;
 }
 
-__global__ __launch_bounds__(256) void k_merge_rank(MergeWideArgs w) {
-    constexpr int TILE = 2048;                 // pool entries staged in LDS at a time
-    __shared__ double s_tile[TILE];
-    const int P = *w.m.n0 + *w.np_out;
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    const int e = g >> 4, slice = g & 15;
-    if ((int)(blockIdx.x * 16) >= P) return;   // uniform: none of the block's 16 elements exists
-    const bool live = e < P;
-    const double ve = live ? w.pool[e] : 0.0;
-    int rank = 0, before = 0;
-    for (int x0 = 0; x0 < P; x0 += TILE) {
-        const int nt = min(TILE, P - x0);
-        __syncthreads();
-        for (int k = threadIdx.x; k < nt; k += 256) s_tile[k] = w.pool[x0 + k];
-        __syncthreads();
-        if (live)
-            for (int k = slice; k < nt; k += 16) {
-                const double vx = s_tile[k];
-                const int x = x0 + k;
-                const int less = vx < ve;
-                rank += less | ((vx == ve) & (x > e));
-                before += less & (x < e);
-            }
+// first index in [lo, hi) whose key is >= v (STRICT = false) / > v (STRICT = true); keys ascending
+template <bool STRICT, class Ptr>
+__device__ __forceinline__ int bound(Ptr key, int lo, int hi, double v) {
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const double k = key[mid];
+        if (STRICT ? (k <= v) : (k < v)) lo = mid + 1; else hi = mid;
     }
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) { rank += __shfl_xor(rank, d, 64); before += __shfl_xor(before, d, 64); }
-    if (live && slice == 0) { w.surv[e] = rank < w.m.cap; w.acc[e] = before < w.m.cap; }
+    return lo;
+}
+// one merge step for the element at sorted position p of a run of length L: where it goes in the merged run of 2 L,
+// and (right-hand runs) how many keys of the left-hand run are strictly smaller
+template <class Ptr>
+__device__ __forceinline__ int merge_place(Ptr key, int p, int L, double v, int* smaller_left) {
+    const int run = p / L, base = (run >> 1) * 2 * L;
+    if (run & 1) {   // right-hand run: behind the left keys that are <= v (the left run holds the earlier pool entries)
+        const int le = bound<true>(key, base, base + L, v) - base;
+        *smaller_left = bound<false>(key, base, base + le, v) - base;
+        return base + (p - (base + L)) + le;
+    }
+    *smaller_left = 0;
+    return base + (p - base) + (bound<false>(key, base + L, base + 2 * L, v) - (base + L));   // behind the right keys that are < v
+}
+
+__global__ __launch_bounds__(256) void k_sort_tiles(MergeWideArgs w) {
+    __shared__ double s_key[2][SORT_TILE];
+    __shared__ int32_t s_idx[2][SORT_TILE];
+    __shared__ int32_t s_before[SORT_TILE];
+    const int P = *w.m.n0 + *w.np_out;
+    const int t0 = blockIdx.x * SORT_TILE;
+    for (int k = threadIdx.x; k < SORT_TILE; k += 256) {
+        const int e = t0 + k;
+        s_key[0][k] = e < P ? w.pool[e] : __builtin_huge_val();
+        s_idx[0][k] = e;
+        s_before[k] = 0;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int L = 1; L < SORT_TILE; L <<= 1) {
+        for (int k = threadIdx.x; k < SORT_TILE; k += 256) {
+            const double v = s_key[cur][k];
+            const int i = s_idx[cur][k];
+            int sm;
+            const int d = merge_place(s_key[cur], k, L, v, &sm);
+            s_key[cur ^ 1][d] = v; s_idx[cur ^ 1][d] = i;
+            if (sm) s_before[i - t0] += sm;      // every element has one thread per level: no two writers
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int k = threadIdx.x; k < SORT_TILE; k += 256) {
+        w.key[0][t0 + k] = s_key[cur][k]; w.idx[0][t0 + k] = s_idx[cur][k];
+        w.before[t0 + k] = s_before[k];
+    }
+}
+
+// one doubling of the run length in global memory: buffer `from` -> the other one
+__global__ __launch_bounds__(256) void k_sort_merge(MergeWideArgs w, int L, int from) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= w.padded) return;
+    const double* key = w.key[from];
+    const double v = key[p];
+    const int i = w.idx[from][p];
+    int sm;
+    int d;
+    const int run = p / L, base = (run >> 1) * 2 * L;
+    if (base + L >= w.padded) { d = p; sm = 0; }     // a last run without a partner moves as it is
+    else {
+        // the partner may be shorter than L (the padded length is a multiple of SORT_TILE, not of 2 L)
+        const int rend = min(base + 2 * L, w.padded);
+        if (run & 1) {
+            const int le = bound<true>(key, base, base + L, v) - base;
+            sm = bound<false>(key, base, base + le, v) - base;
+            d = base + (p - (base + L)) + le;
+        } else {
+            sm = 0;
+            d = base + (p - base) + (bound<false>(key, base + L, rend, v) - (base + L));
+        }
+    }
+    w.key[from ^ 1][d] = v; w.idx[from ^ 1][d] = i;
+    if (sm) w.before[i] += sm;
+}
+
+// the two decisions of the merge from the sorted pool (buffer `in`)
+__global__ __launch_bounds__(256) void k_sort_ranks(MergeWideArgs w, int in) {
+    const int P = *w.m.n0 + *w.np_out;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const double* key = w.key[in];
+    const double v = key[p];
+    const int lo = bound<false>(key, 0, P, v), hi = bound<true>(key, lo, P, v);
+    const int rank = lo + (hi - 1 - p);            // ties reversed: among equal keys the later pool entry ranks first
+    const int i = w.idx[in][p];
+    w.surv[i] = rank < w.m.cap;
+    w.acc[i] = w.before[i] < w.m.cap;
 }
 
 __global__ __launch_bounds__(1024) void k_merge_write(MergeWideArgs w) {
@@ -447,6 +525,7 @@ struct vo_frame_state {
     float *score, *su, *sv;
     uint8_t *valid, *cvalid, *cok, *alive, *inl;
     int32_t *pos, *plist, *counts2[2], *slin;   // counts2: a frame's counters, by frame parity
+    double* skey; int32_t *sidx, *sbefore; int sort_padded;   // the wide merge's sort: two key / index buffers, the `before` counts
     int32_t* sizes;                         // device: {landmarks, candidates} of state s (k_append_new / set_state)
     int32_t* h_counts;                      // pinned
     double* h_rec;                          // pinned: VO_FRAME_MAX_PENDING records of 40 doubles (ransac record 16, pose 12, counters)
@@ -494,6 +573,8 @@ void carve(vo_frame_state* st, char* base, size_t* total) {
     st->su = b.take<float>(keep); st->sv = b.take<float>(keep); st->slin = b.take<int32_t>(keep);
     st->valid = b.take<uint8_t>(pw); st->cvalid = b.take<uint8_t>(cc); st->cok = b.take<uint8_t>(cc);
     st->alive = b.take<uint8_t>(pw); st->inl = b.take<uint8_t>(cl);
+    st->skey = b.take<double>(2 * (size_t)st->sort_padded); st->sidx = b.take<int32_t>(2 * (size_t)st->sort_padded);
+    st->sbefore = b.take<int32_t>((size_t)st->sort_padded);
     st->pos = b.take<int32_t>(pw); st->plist = b.take<int32_t>(cc); st->counts2[0] = b.take<int32_t>(16); st->counts2[1] = b.take<int32_t>(16);
     st->sizes = b.take<int32_t>(16);
     *total = b.off + 256;
@@ -538,6 +619,7 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     st->o = *o; st->nu = nu; st->nv = nv;
     st->capL = o->max_landmarks; st->capC = o->max_candidates; st->PW = st->capL + st->capC;
     st->ring = o->max_temporal_recall + 2; st->P = st->ring + o->max_temporal_recall + 64;
+    st->sort_padded = (st->PW + SORT_TILE - 1) / SORT_TILE * SORT_TILE;
     st->cur = 0; st->have_prev = false; st->nL = st->nC = 0; st->frame_no = 0; st->s = 0;
     st->arena = nullptr; st->img[0] = st->img[1] = st->img[2] = nullptr; st->h_counts = nullptr; st->h_rec = nullptr;
     size_t total = 0;
@@ -878,9 +960,15 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         if (pw <= MERGE_LDS && nL_hint + nC_hint + VO_FRAME_MAX_PENDING * o.sel.keep <= MERGE_ONE_BLOCK) {
             hipLaunchKernelGGL(k_merge_par, dim3(2), dim3(1024), 0, sm, m, cop, cc, counts + 1, lop, counts + 0, st->sizes);
         } else {                                               // the all-pairs counts spread over the chip
-            MergeWideArgs mw = {m, st->pin, (uint8_t*)st->pos, (uint8_t*)st->pos + pw, counts + 9};
+            const int padded = st->sort_padded;
+            MergeWideArgs mw = {m, st->pin, (uint8_t*)st->pos, (uint8_t*)st->pos + pw, counts + 9,
+                                {st->skey, st->skey + padded}, {st->sidx, st->sidx + padded}, st->sbefore, padded};
             hipLaunchKernelGGL(k_merge_list, dim3(1), dim3(1024), 0, sm, mw);
-            hipLaunchKernelGGL(k_merge_rank, dim3(blocks(16 * pw)), dim3(256), 0, sm, mw);
+            hipLaunchKernelGGL(k_sort_tiles, dim3(padded / SORT_TILE), dim3(256), 0, sm, mw);
+            int from = 0;
+            for (int L = SORT_TILE; L < padded; L <<= 1, from ^= 1)
+                hipLaunchKernelGGL(k_sort_merge, dim3(blocks(padded)), dim3(256), 0, sm, mw, L, from);
+            hipLaunchKernelGGL(k_sort_ranks, dim3(blocks(pw)), dim3(256), 0, sm, mw, from);
             hipLaunchKernelGGL(k_merge_write, dim3(1), dim3(1024), 0, sm, mw);
             hipLaunchKernelGGL((k_compact2<CandOp, LandmarkOp>), dim3(2), dim3(1024), 0, sm, cop, cc, counts + 1, st->sizes + 1, lop, pw, counts + 0,
                                st->sizes + 0, cl);
@@ -938,6 +1026,40 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         st->next_src = nullptr;
     }
     ST_CHECK(hipGetLastError());
+    return VO_OK;
+}
+
+// The two decisions of the merge policy for a pool given as such (see include/vo_hip.h): the sort-based form that
+// vo_frame_submit uses for large pools, on the caller's values.
+int vo_dev_merge_ranks(vo_ctx* ctx, const double* d_values, int n0, int np, int cap, uint8_t* d_survives, uint8_t* d_accepted) {
+    if (!ctx || n0 < 0 || np < 0 || cap < 0) return VO_ERR_BAD_ARG;
+    const long P = (long)n0 + np;
+    if (P == 0) return VO_OK;
+    if (!d_values || !d_survives || !d_accepted || P > (1l << 26)) return VO_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    const int padded = (int)((P + SORT_TILE - 1) / SORT_TILE * SORT_TILE);
+    // work: the pool in place (the caller's array), two key and two index buffers, the counts, n0 and np on the device
+    const size_t bytes = (size_t)padded * (2 * 8 + 2 * 4 + 4) + 5 * 256;
+    int rc = vo_buf_reserve(ctx, &ctx->scratch[19], bytes);
+    if (rc) return rc;
+    Bump b; b.base = (char*)ctx->scratch[19].p;
+    MergeWideArgs mw = {};
+    mw.key[0] = b.take<double>(padded); mw.key[1] = b.take<double>(padded);
+    mw.idx[0] = b.take<int32_t>(padded); mw.idx[1] = b.take<int32_t>(padded);
+    mw.before = b.take<int32_t>(padded);
+    int32_t* d_n = b.take<int32_t>(2);
+    const int32_t hn[2] = {n0, np};
+    ST_CHECK(hipMemcpyAsync(d_n, hn, sizeof hn, hipMemcpyHostToDevice, ctx->stream));
+    mw.m.n0 = d_n; mw.np_out = d_n + 1; mw.m.cap = cap;
+    mw.pool = const_cast<double*>(d_values); mw.surv = d_survives; mw.acc = d_accepted; mw.padded = padded;
+    hipStream_t sm = ctx->stream;
+    hipLaunchKernelGGL(k_sort_tiles, dim3(padded / SORT_TILE), dim3(256), 0, sm, mw);
+    int from = 0;
+    for (int L = SORT_TILE; L < padded; L <<= 1, from ^= 1)
+        hipLaunchKernelGGL(k_sort_merge, dim3(blocks(padded)), dim3(256), 0, sm, mw, L, from);
+    hipLaunchKernelGGL(k_sort_ranks, dim3(blocks((int)P)), dim3(256), 0, sm, mw, from);
+    ST_CHECK(hipGetLastError());
+    ST_CHECK(hipStreamSynchronize(sm));   // hn lives on this frame of the stack
     return VO_OK;
 }
 
