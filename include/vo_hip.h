@@ -146,6 +146,12 @@ int vo_timer_lap_begin(vo_ctx* ctx);
 int vo_timer_lap_end(vo_ctx* ctx);
 int vo_timer_laps_ms(vo_ctx* ctx, float* total_ms, int* laps);
 
+/* measurement of the pose step's scoring kernel: while on, every k_score launch of this ctx is one lap of the stopwatch
+ * above (read the sum with vo_timer_laps_ms) and counts the pose x point inlier tests it executes (26 fp64 flop each:
+ * 11 fused multiply-adds, 3 multiplications, 1 compare); vo_ctx_read_score_tests returns the count (synchronises) */
+int vo_ctx_time_score(vo_ctx* ctx, int on);
+int vo_ctx_read_score_tests(vo_ctx* ctx, uint64_t* tests, int reset);
+
 /* ==== host-pointer entry points (what the MEX gateways bind) ==== */
 
 /* KLTTracker.track, modules/KLTTracker.m:22-41.  pts: N x 2 [x y]; outputs follow the class of

@@ -353,6 +353,24 @@ int vo_timer_stop_ms(vo_ctx* ctx, float* ms) {
     return VO_OK;
 }
 
+// measurement of the pose step's scoring kernel (bench.py): while on, every k_score launch is a lap of the stopwatch below
+// and adds the pose x point tests it executes to one word; vo_ctx_read_score_tests returns (and clears) the count
+int vo_ctx_time_score(vo_ctx* ctx, int on) {
+    if (!ctx) return VO_ERR_BAD_ARG;
+    ctx->time_score = on != 0;
+    return VO_OK;
+}
+int vo_ctx_read_score_tests(vo_ctx* ctx, uint64_t* tests, int reset) {
+    if (!ctx || !tests) return VO_ERR_BAD_ARG;
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(vo_int_head_words(ctx)) + 64);
+    unsigned long long h = 0;
+    VO_HIP_CHECK(ctx, hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) VO_HIP_CHECK(ctx, hipMemsetAsync(d, 0, sizeof h, ctx->stream));
+    VO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *tests = h;
+    return VO_OK;
+}
+
 // laps: many intervals on the ctx stream, read back with ONE synchronisation (the host never idles the GPU
 // between the intervals, so the kernels inside see the clocks of a saturated device)
 int vo_timer_lap_begin(vo_ctx* ctx) {

@@ -69,6 +69,7 @@ struct vo_ctx {
     uint64_t clock = 0;
     unsigned long long* d_counters = nullptr; // VO_COUNTER_SHARDS x 4 u64
     vo_buf scratch[20];                        // purpose-indexed scratch (see vo_api.hip; [16] = vo_rgb2gray staging, [17] = second selection set, [18] = response / greedy entry points, [19] = vo_dev_merge_ranks)
+    bool time_score = false;   // vo_ctx_time_score: laps around the pose step's k_score launches + a count of their tests
     bool head_open = false;    // a vo_dev_klt_track_head launch has been enqueued (vo_dev_wait_head may follow)
     unsigned head_epoch = 0;   // vo_dev_klt_track_head launches so far (the flag word holds the last finished one's number)
     std::string last_error;

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a, CandOp cop, int
 // (never below or equal to a real key: reproError is finite wherever the classes let a candidate in).
 // pool: the keys in pool order; key / idx: two buffers each of the padded length; before: one int per pool entry.
 struct MergeWideArgs { MergeArgs m; double* pool; uint8_t *surv, *acc; int32_t* np_out; double* key[2]; int32_t* idx[2]; int32_t* before; int padded; };
-constexpr int SORT_TILE = 2048;     // elements sorted by one block in LDS (8 per thread)
+constexpr int SORT_TILE = 2048;     // elements sorted by one block in LDS (2 per thread: every step of a level is a chain of dependent LDS reads)
 
 __global__ __launch_bounds__(1024) void k_merge_list(MergeWideArgs w) {
     __shared__ int s_w[16];
@@ -357,13 +357,13 @@ __device__ __forceinline__ int merge_place(Ptr key, int p, int L, double v, int*
     return base + (p - base) + (bound<false>(key, base + L, base + 2 * L, v) - (base + L));   // behind the right keys that are < v
 }
 
-__global__ __launch_bounds__(256) void k_sort_tiles(MergeWideArgs w) {
+__global__ __launch_bounds__(1024) void k_sort_tiles(MergeWideArgs w) {
     __shared__ double s_key[2][SORT_TILE];
     __shared__ int32_t s_idx[2][SORT_TILE];
     __shared__ int32_t s_before[SORT_TILE];
     const int P = *w.m.n0 + *w.np_out;
     const int t0 = blockIdx.x * SORT_TILE;
-    for (int k = threadIdx.x; k < SORT_TILE; k += 256) {
+    for (int k = threadIdx.x; k < SORT_TILE; k += 1024) {
         const int e = t0 + k;
         s_key[0][k] = e < P ? w.pool[e] : __builtin_huge_val();
         s_idx[0][k] = e;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_sort_tiles(MergeWideArgs w) {
     __syncthreads();
     int cur = 0;
     for (int L = 1; L < SORT_TILE; L <<= 1) {
-        for (int k = threadIdx.x; k < SORT_TILE; k += 256) {
+        for (int k = threadIdx.x; k < SORT_TILE; k += 1024) {
             const double v = s_key[cur][k];
             const int i = s_idx[cur][k];
             int sm;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_sort_tiles(MergeWideArgs w) {
         __syncthreads();
         cur ^= 1;
     }
-    for (int k = threadIdx.x; k < SORT_TILE; k += 256) {
+    for (int k = threadIdx.x; k < SORT_TILE; k += 1024) {
         w.key[0][t0 + k] = s_key[cur][k]; w.idx[0][t0 + k] = s_idx[cur][k];
         w.before[t0 + k] = s_before[k];
     }
@@ -964,7 +964,7 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
             MergeWideArgs mw = {m, st->pin, (uint8_t*)st->pos, (uint8_t*)st->pos + pw, counts + 9,
                                 {st->skey, st->skey + padded}, {st->sidx, st->sidx + padded}, st->sbefore, padded};
             hipLaunchKernelGGL(k_merge_list, dim3(1), dim3(1024), 0, sm, mw);
-            hipLaunchKernelGGL(k_sort_tiles, dim3(padded / SORT_TILE), dim3(256), 0, sm, mw);
+            hipLaunchKernelGGL(k_sort_tiles, dim3(padded / SORT_TILE), dim3(1024), 0, sm, mw);
             int from = 0;
             for (int L = SORT_TILE; L < padded; L <<= 1, from ^= 1)
                 hipLaunchKernelGGL(k_sort_merge, dim3(blocks(padded)), dim3(256), 0, sm, mw, L, from);
@@ -1053,7 +1053,7 @@ int vo_dev_merge_ranks(vo_ctx* ctx, const double* d_values, int n0, int np, int 
     mw.m.n0 = d_n; mw.np_out = d_n + 1; mw.m.cap = cap;
     mw.pool = const_cast<double*>(d_values); mw.surv = d_survives; mw.acc = d_accepted; mw.padded = padded;
     hipStream_t sm = ctx->stream;
-    hipLaunchKernelGGL(k_sort_tiles, dim3(padded / SORT_TILE), dim3(256), 0, sm, mw);
+    hipLaunchKernelGGL(k_sort_tiles, dim3(padded / SORT_TILE), dim3(1024), 0, sm, mw);
     int from = 0;
     for (int L = SORT_TILE; L < padded; L <<= 1, from ^= 1)
         hipLaunchKernelGGL(k_sort_merge, dim3(blocks(padded)), dim3(256), 0, sm, mw, L, from);

@@ -382,6 +382,7 @@ struct ScoreArgs {
     const int32_t* qdev;    // the two sieve marks of a staged run, chosen on the device by the first stage's k_best
     const int32_t* stopped; // as in HypArgs
     const int32_t* M_dev;   // as in HypArgs
+    unsigned long long* tests;   // optional: one word that counts the pose x point tests executed (bench.py's k_score roofline)
 };
 
 // Scores 8 poses per block on a range of the points and ADDS what it finds to cnt / cost (zeroed by k_zero):
@@ -482,6 +483,11 @@ __device__ __forceinline__ void score_body(ScoreArgs a, const double* own_poses)
     }
     if (tid == 0 && a.counters && !a.list && blockIdx.y == 0)
         atomicAdd(&a.counters[4 * (blockIdx.x & (VO_COUNTER_SHARDS - 1)) + 3], (unsigned long long)min(SC_HB, a.H - (a.h0 + (int)blockIdx.x * SC_HB)));
+    if (tid == 0 && a.tests) {
+        int live = 0;
+        for (int s = 0; s < SC_NS; ++s) live += s_pid[s] >= 0;
+        atomicAdd(a.tests, (unsigned long long)live * (unsigned long long)(c1 - c0));
+    }
 }
 __global__ __launch_bounds__(SC_NT) void k_score(ScoreArgs a) {
     VO_POSE_PRIO();
@@ -821,13 +827,17 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
         s.cnt = w->cnt; s.cost = w->cost; s.counters = ctx->d_counters; s.h0 = h0; s.stopped = later ? stopped : nullptr; s.M_dev = d_M;
         s.list = from_list == 0 ? nullptr : (from_list == 1 ? w->list : w->list + 4 * (size_t)H);
         s.list_n = w->list_n + (from_list == 2 ? 1 : 0); s.q0 = q0; s.q1 = q1; s.qdev = marks ? sieve : nullptr;
+        s.tests = ctx->time_score ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(vo_int_head_words(ctx)) + 64) : nullptr;
         const int nb = (h1 - h0 + SC_HB - 1) / SC_HB;
         // survivor launches: few blocks do anything (how few is known on the device only), so each takes a short
         // piece of the range -- the launch is as long as one block
         // points of the range: known here only without marks; with them about a third of the points
         const int npts = marks ? M / 3 : (int)((long)M * (q1 - q0) / 64);
         const int chunks = from_list ? (npts >= 16 * 512 ? 16 : (npts >= 2048 ? 4 : 1)) : score_chunks(nb, npts);
+        // vo_ctx_time_score: a lap of the ctx's event stopwatch around every k_score launch (bench.py's roofline entry)
+        if (ctx->time_score) (void)vo_timer_lap_begin(ctx);
         hipLaunchKernelGGL(k_score, dim3(nb, chunks), dim3(SC_NT), 0, ctx->stream, s);
+        if (ctx->time_score) (void)vo_timer_lap_end(ctx);
     };
     auto best = [&](int h1, int later, bool write_bound) {
         BestArgs b;
@@ -852,7 +862,7 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
         ScoreArgs& sc = sa.s;
         sc.xy = d_xy; sc.sxy = sxy; sc.X = d_X; sc.sX = sX; sc.M = M; sc.K = d_K; sc.H = h1; sc.thr2 = thr2; sc.Rt = w->Rt;
         sc.cnt = w->cnt; sc.cost = w->cost; sc.counters = ctx->d_counters; sc.h0 = h0; sc.stopped = nullptr; sc.M_dev = d_M;
-        sc.list = nullptr; sc.list_n = nullptr; sc.q0 = 0; sc.q1 = 64; sc.qdev = nullptr;
+        sc.list = nullptr; sc.list_n = nullptr; sc.q0 = 0; sc.q1 = 64; sc.qdev = nullptr; sc.tests = nullptr;
         BestArgs& b = sa.b;
         b.cnt = w->cnt; b.cost = w->cost; b.Rt = w->Rt; b.H = h1; b.M = M; b.mode = o->mode; b.min_inl = o->min_inliers;
         b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 3; b.later_stage = later ? 1 : 0; b.M_dev = d_M;

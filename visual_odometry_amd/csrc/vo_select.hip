@@ -281,7 +281,12 @@ __device__ __forceinline__ int grid_cell1(float x, float inv_cs, int g) {
 }
 
 // ---- N7 detection.  One block = 1024 consecutive linear indices; pass 0 counts, pass 1 writes.
-constexpr int DT_BLOCK = 1024;
+// One-wave workgroups without LDS for the three kernels that follow the response in the image-only half (round 3): the
+// half runs a frame ahead on the side stream and, when it outlasts the tail it starts in, beside the NEXT tracking launch,
+// which holds every wave slot and all but 3.6 KB of each CU's LDS.  A block of sixteen waves then waited until the
+// tracking launch had drained (k_detect 0.11 ms on average, 1 ms at worst, and the selection's filter half waited for
+// the end of the chain in the next tail); a one-wave block takes the first slot a finished keypoint leaves.
+constexpr int DT_BLOCK = 64;
 
 __device__ __forceinline__ bool is_corner(const double* __restrict__ resp, int nu, int nv, long i, double thr) {
     const int v = (int)(i / nu), u = (int)(i - (long)v * nu);
@@ -306,27 +311,18 @@ __global__ __launch_bounds__(DT_BLOCK) void k_detect(const double* __restrict__ 
                                                       const int32_t* __restrict__ blk_offs, int cap,
                                                       int32_t* lin, float* lu, float* lv, double* metric,
                                                       GridArgs g, uint8_t* keep) {
-    __shared__ int wave_cnt[DT_BLOCK / 64];
     const long n = (long)nu * nv;
     const long i = (long)blockIdx.x * DT_BLOCK + threadIdx.x;
     const double thr = min_quality * __longlong_as_double((long long)*maxbits);
     const bool c = i < n && is_corner(resp, nu, nv, i, thr);
     const unsigned long long bal = __ballot(c);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) wave_cnt[wid] = __popcll(bal);
-    __syncthreads();
+    const int lane = threadIdx.x;
     if (pass == 0) {
-        if (threadIdx.x == 0) {
-            int t = 0;
-            for (int w = 0; w < DT_BLOCK / 64; ++w) t += wave_cnt[w];
-            blk_counts[blockIdx.x] = t;
-        }
+        if (lane == 0) blk_counts[blockIdx.x] = __popcll(bal);
         return;
     }
     if (!c) return;
-    int pos = blk_offs[blockIdx.x];
-    for (int w = 0; w < wid; ++w) pos += wave_cnt[w];
-    pos += __popcll(bal & ((1ull << lane) - 1ull));
+    const int pos = blk_offs[blockIdx.x] + __popcll(bal & ((1ull << lane) - 1ull));
     if (pos >= cap) return;
     const int v = (int)(i / nu), u = (int)(i - (long)v * nu);
     const double r = resp[i];
@@ -344,47 +340,43 @@ __global__ __launch_bounds__(DT_BLOCK) void k_detect(const double* __restrict__ 
     atomicAdd(&g.count[grid_cell1(fv, g.inv_cs, g.gv) * g.gu + grid_cell1(fu, g.inv_cs, g.gu)], 1);
 }
 
-// exclusive scan of the per-block counts (single block), total -> *m0 (clamped to cap)
-constexpr int SCAN_LDS = 8192;   // entries staged through LDS (coalesced global reads and writes)
-__global__ __launch_bounds__(1024) void k_scan_counts(const int32_t* __restrict__ counts, int nblk, int32_t* offs,
-                                                       int32_t* m0, int cap) {
-    // exclusive prefix sums of `counts` (each thread owns `per` consecutive entries): wave scan by shuffles, the
-    // 16 wave totals through LDS.  Up to SCAN_LDS entries the table goes through LDS, so that global memory sees
-    // coalesced rows instead of 2 x per strided accesses per thread (latency, not bytes, is what this kernel costs).
-    __shared__ int s_wave[16];
-    __shared__ int s_tab[SCAN_LDS];
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int per = (nblk + 1023) / 1024;
-    const bool staged = nblk <= SCAN_LDS;
-    if (staged) {
-        for (int i = t; i < nblk; i += 1024) s_tab[i] = counts[i];
-        __syncthreads();
-    }
-    int s = 0;
-    for (int k = 0; k < per; ++k) { int i = t * per + k; if (i < nblk) s += staged ? s_tab[i] : counts[i]; }
-    int inc = s;
+// exclusive scan of a table of counts by ONE wave, total -> *m0 (clamped to cap): 256 entries a step (four per lane in
+// one 16-byte load, the next step's load in flight while this step's wave scan runs), the running total carried in a
+// scalar.  ~30 steps for a KITTI frame's 7.3k blocks or 7.7k grid cells.
+__global__ __launch_bounds__(64) void k_scan_counts(const int32_t* __restrict__ counts, int n, int32_t* offs,
+                                                     int32_t* m0, int cap) {
+    const int lane = threadIdx.x;
+    auto load4 = [&](int i, int (&c)[4]) {
+        if (i + 3 < n) { const int4 v = *reinterpret_cast<const int4*>(counts + i); c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w; }
+        else for (int k = 0; k < 4; ++k) c[k] = i + k < n ? counts[i + k] : 0;
+    };
+    int carry = 0;
+    int nxt[4];
+    load4(4 * lane, nxt);
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + 4 * lane;
+        const int c0 = nxt[0], c1 = nxt[1], c2 = nxt[2], c3 = nxt[3];
+        if (base + 256 < n) load4(i + 256, nxt);
+        const int s = (c0 + c1) + (c2 + c3);
+        int inc = s;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-    if (lane == 63) s_wave[wid] = inc;
-    __syncthreads();
-    int before = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) { const int c = s_wave[w]; if (w < wid) before += c; total += c; }
-    int run = before + inc - s;
-    if (staged) {
-        for (int k = 0; k < per; ++k) { int i = t * per + k; if (i < nblk) { const int c = s_tab[i]; s_tab[i] = run; run += c; } }
-        __syncthreads();
-        for (int i = t; i < nblk; i += 1024) offs[i] = s_tab[i];
-    } else {
-        for (int k = 0; k < per; ++k) { int i = t * per + k; if (i < nblk) { offs[i] = run; run += counts[i]; } }
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        const int run = carry + inc - s;
+        if (i + 3 < n) *reinterpret_cast<int4*>(offs + i) = make_int4(run, run + c0, run + c0 + c1, run + c0 + c1 + c2);
+        else {
+            if (i < n) offs[i] = run;
+            if (i + 1 < n) offs[i + 1] = run + c0;
+            if (i + 2 < n) offs[i + 2] = run + c0 + c1;
+        }
+        carry += __builtin_amdgcn_readlane(inc, 63);
     }
-    if (t == 0) *m0 = total < cap ? total : cap;
+    if (lane == 0) *m0 = carry < cap ? carry : cap;
 }
 
 // second half of the counting sort: corner i goes to its cell's span of the sorted arrays
-__global__ __launch_bounds__(256) void k_grid_fill(const float* __restrict__ cu, const float* __restrict__ cv,
-                                                    const int32_t* __restrict__ m0, GridArgs g) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void k_grid_fill(const float* __restrict__ cu, const float* __restrict__ cv,
+                                                   const int32_t* __restrict__ m0, GridArgs g) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= *m0) return;
     const float u = cu[i], v = cv[i];
     const int c = grid_cell1(v, g.inv_cs, g.gv) * g.gu + grid_cell1(u, g.inv_cs, g.gu);
@@ -897,13 +889,13 @@ int vo_launch_select_detect(vo_ctx* ctx, hipStream_t stream, const uint8_t* d_im
     const GridArgs g = grid_args(w);
     hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, stream, w->resp, nu, nv, w->maxbits,
                        o->min_quality, 0, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric, g, w->keep);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, w->blk_counts, nblk, w->blk_offs, w->m0, w->cap);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(64), 0, stream, w->blk_counts, nblk, w->blk_offs, w->m0, w->cap);
     hipLaunchKernelGGL(k_detect, dim3(nblk), dim3(DT_BLOCK), 0, stream, w->resp, nu, nv, w->maxbits,
                        o->min_quality, 1, w->blk_counts, w->blk_offs, w->cap, w->lin, w->lu, w->lv, w->metric, g, w->keep);
     // the corner grid of the distance filter: counted by the write pass above, scanned and filled here
     const int ncell = g.gu * g.gv;
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, stream, g.count, ncell, g.offs, w->grid_total, 0x7fffffff);
-    hipLaunchKernelGGL(k_grid_fill, dim3((w->cap + 255) / 256), dim3(256), 0, stream, w->lu, w->lv, w->m0, g);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(64), 0, stream, g.count, ncell, g.offs, w->grid_total, 0x7fffffff);
+    hipLaunchKernelGGL(k_grid_fill, dim3((w->cap + 63) / 64), dim3(64), 0, stream, w->lu, w->lv, w->m0, g);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }
