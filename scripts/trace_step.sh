@@ -10,7 +10,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 lk = [i for i, r in enumerate(rows) if "k_lk" in r["Kernel_Name"]]
-i0, i1 = lk[-124], lk[-120] + 1                # inside the K timed steps (behind them come 90 roofline-leg launches): two steps
+i0, i1 = lk[-50], lk[-48]                      # two whole steps among the 60 untimed steps in front of the roofline leg (same schedule as the timed ones; one tracking launch a step since round 3)
 t0 = int(rows[i0]["Start_Timestamp"])
 prev_end = None
 for r in rows[i0:i1 + 1]:
