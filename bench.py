@@ -6,10 +6,11 @@
 
 One step = the hot path of one VO frame with every input resident in HBM (visual_odometry_amd/
 device.py): pyramid build, KLT track of the landmark and of the candidate keypoints, P3P-RANSAC pose,
-batched triangulation, candidate selection.  Schedule (FrameWorkload.step_ahead): the landmark track and the pose
-chain that depends on it run on the ctx's high-priority lane stream beside the candidate track on the main stream
-(modules/VisualOdometry.m:278-289 need nothing of :71), triangulation and the selection's filter half follow on the
-main stream, and the next frame's pyramid and corner detection are issued on the side stream into that tail.  Default workload = BASELINE.json configs[3] (synthetic
+batched triangulation, candidate selection.  Schedule (FrameWorkload.step_ahead): landmarks and candidates are ONE
+tracking launch with the landmarks as its head; when the head is out, the pose chain that depends on it starts on the
+ctx's lane stream beside the candidates' half (modules/VisualOdometry.m:278-289 need nothing of :71) -- every stream at
+normal priority; triangulation and the selection's filter half follow on the main stream, and the next frame's pyramid
+and corner detection are issued on the side stream beside the tracking launch.  Default workload = BASELINE.json configs[3] (synthetic
 1241x376, 50k keypoints per frame split into 25k landmarks + 25k candidates, 4 levels, 2k RANSAC
 hypotheses) -- the configuration the north-star target is quoted on.  N > 1: every rank runs its own
 seed-offset sequence (weak scaling, no data-path collective); RCCL gathers the statistics once.
@@ -321,9 +322,8 @@ def main():
     # N > 1 code path on a one-GPU box (the numbers mean nothing); never set by the driver
     rehearse = bool(os.environ.get("VO_REHEARSE_ONE_GPU"))
     if rehearse:
-        # several processes on ONE GPU: the ctx's high-priority lane stream of one process starves the other's streams
-        # for good (a hang, found by this rehearsal); at the ctx stream's priority they get along.  One process per GPU
-        # -- what --gpus N runs everywhere else -- is not affected.
+        # several processes on ONE GPU: a high-priority lane stream of one process starved the other's streams for good
+        # (a hang, found by this rehearsal in round 2; the library now refuses the priority there) -- never asked for here
         os.environ.setdefault("VO_LANE_NORMAL_PRIORITY", "1")
     rank, local_rank, world = dist.init("gloo" if rehearse else None)
     if rehearse:
@@ -339,8 +339,11 @@ def main():
     ctx = _lib.Context(local_rank)
     nl = args.keypoints // 2
     nc = args.keypoints - nl
-    # one ctx per process and one process per GPU: the lane may be a high-priority stream (not in the one-GPU rehearsal)
-    wl = FrameWorkload(ctx, nl, nc, num_hyp=args.hyp, seed=1023 + 7919 * rank, lane_priority=not os.environ.get("VO_REHEARSE_ONE_GPU"))
+    # default configuration: every stream at normal priority (vo_ctx_lane_priority is not asked for; VO_LANE_PRIORITY=1
+    # asks for it, an A/B switch).  The pose chain gets the landmark tracks early by ORDER: they are the head of the
+    # one tracking launch (vo_dev_klt_track_head), and the lane's chain starts when the head is out.
+    wl = FrameWorkload(ctx, nl, nc, num_hyp=args.hyp, seed=1023 + 7919 * rank,
+                       lane_priority=bool(os.environ.get("VO_LANE_PRIORITY")) and not rehearse)
 
     # Device spin-up, untimed and before the W warm-up steps: the first few hundred milliseconds after an idle
     # period run ~3 % slower than the steady state (clocks / power state: 1.26-1.27 ms per step right after the
@@ -387,13 +390,13 @@ def main():
         flops = WINDOW_PX * (FLOP_ITER_PX * it + FLOP_SETUP_PX * su) / (respin + reps)   # the counters saw every launch since the reset
         ach = flops / (ms * 1e-3) / 1e12
         # HBM-side bytes per launch and the VALU issue utilisation come from the rocprofv3 --pmc passes over this same
-        # kernel and workload (scripts/profile_round.sh -> profiles/round2_k_lk_pmc.json); they are quoted only while the
+        # kernel and workload (scripts/profile_round.sh -> profiles/round3_k_lk_pmc.json); they are quoted only while the
         # kernel's sources are the ones that were profiled (sha256 in the file)
         traffic = valu_util = None
         pmc_note = "no PMC summary for this build of k_lk: traffic and valu_util not quoted"
         try:
             import hashlib
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_k_lk_pmc.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round3_k_lk_pmc.json")))
             sha = hashlib.sha256()
             for f in ("vo_klt.hip", "vo_image.hip", "vo_common.h"):
                 sha.update(open(os.path.join(ROOT, "visual_odometry_amd", "csrc", f), "rb").read())
@@ -402,7 +405,7 @@ def main():
                 valu_util = pmc.get("valu_issue_util")
                 pmc_note = ("traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch (fabric-side, Infinity-Cache hits included; "
                             "FETCH_SIZE doubled for the 16-B/lane loads) and valu_util = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x "
-                            "GRBM_GUI_ACTIVE / 8) from profiles/round2_k_lk_pmc.json, PMC passes of this same kernel source; by the same "
+                            "GRBM_GUI_ACTIVE / 8) from profiles/round3_k_lk_pmc.json, PMC passes of this same kernel source; by the same "
                             "formula a kernel of nothing but v_fma_f32 reaches 0.67 at this kernel's 4 waves per SIMD and 0.75-0.82 "
                             "at 8 (profiles/round2_valu_clock_pmc.txt)")
         except (OSError, ValueError, KeyError):
@@ -416,7 +419,7 @@ def main():
                         "flops = 1681 px x (11/iteration + 24/set-up), SURVEY 8d: ALGORITHMIC flops, the correlation-cell "
                         "formulation executes fewer; launch_ms = HIP events around ONE 50k-keypoint launch (landmarks + candidates, "
                         "nothing beside it) inside whole frame steps, read back once at the end -- the timed steps above run the "
-                        "two sets as two 25k launches on two streams beside the pose chain; " + pmc_note}
+                        "same launch with the pose chain beside its second half (profiles/round3_k_lk_by_grid.txt has both); " + pmc_note}
         wl.drain()              # single stages from here on: finish what was begun ahead
         a, b = wl.k % 2, (wl.k + 1) % 2
         for name, fn in (("pyramid", lambda: wl.build(b, (wl.k % wl.n_frames) + 1)), ("klt_landmarks+candidates", lambda: wl.track_all(a, b)),
@@ -480,9 +483,11 @@ def main():
                                        f"{args.keypoints} keypoints/frame ({nl} landmarks + {nc} candidates), 4-level pyramid, "
                                        f"41x41 window, <=50 iterations, fwd-bwd 2 px, {args.hyp} P3P-RANSAC hypotheses (MSAC) on the "
                                        "landmarks, batched triangulation of the candidates, min-eigen selection (keep 100)",
-                           "schedule": "landmark track -> pose chain on a high-priority stream beside the candidate track; "
-                                       "triangulation and selection filter behind both; next frame's pyramid and corner "
-                                       "detection issued ahead into that tail (VO_NO_LANE=1 / VO_NO_PREFETCH=1 switch them off)",
+                           "schedule": "one tracking launch, landmarks first; when that head is out the pose chain starts on a "
+                                       "second stream of the same (normal) priority beside the candidates' half; triangulation "
+                                       "and selection filter behind both; next frame's pyramid and corner detection issued ahead "
+                                       "beside the tracking launch (VO_NO_HEAD=1 / VO_NO_LANE=1 / VO_NO_PREFETCH=1 switch them off)",
+                           "lane_priority": bool(os.environ.get("VO_LANE_PRIORITY")) and not rehearse,
                            "keypoints_per_frame": args.keypoints, "hypotheses": args.hyp,
                            "parallelism": f"{world} independent sequence(s), one per GPU"},
                 # every rank's own time per step (min / max / each, rank order): ms_per_step above is the slowest rank's

@@ -30,10 +30,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     k.eps = 0.01;
     plhs[0] = mxCreateNumericMatrix(N, 2, cls, mxREAL);
     mxArray* valid = mxCreateLogicalMatrix(N, 1);
-    mxArray* score = mxCreateNumericMatrix(N, 1, cls, mxREAL);
+    mxArray* score = nlhs > 2 ? mxCreateNumericMatrix(N, 1, cls, mxREAL) : nullptr; // scores are only computed when asked for
     vo_mex_check(vo_klt_track(vo_mex_ctx(), (const uint8_t*)mxGetData(i1), (const uint8_t*)mxGetData(i2), H, W, VO_MATLAB,
                               mxGetData(p), N, dbl ? 1 : 0, &k, mxGetData(plhs[0]), (uint8_t*)mxGetData(valid),
-                              mxGetData(score)), "vo_klt_track");
+                              score ? mxGetData(score) : nullptr), "vo_klt_track");
     if (nlhs > 1) plhs[1] = valid; else mxDestroyArray(valid);
-    if (nlhs > 2) plhs[2] = score; else mxDestroyArray(score);
+    if (nlhs > 2) plhs[2] = score;
 }

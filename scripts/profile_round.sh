@@ -24,17 +24,25 @@ cp $(find $O/trace -name "*kernel_stats.csv") $O/kernel_stats.csv
 cp $(find $O/frame_trace -name "*kernel_stats.csv") $O/frame_loop_kernel_stats.csv
 python3 scripts/pmc_summary.py k_lk $(find $O -name "*counter_collection.csv") > $O/k_lk_pmc.txt
 python3 scripts/pmc_json.py 50000 4 $(find $O -name "*counter_collection.csv") > $O/k_lk_pmc.json
-# the tracking launches of the profiled bench by grid size: 50k-keypoint launches (roofline leg, alone on the chip) and
-# 25k-keypoint launches (timed steps: landmarks on the lane stream beside candidates on the ctx stream)
+# the tracking launches of the profiled bench by grid size, and the 50k-keypoint launches by what ran beside them: alone
+# on the chip (the roofline leg's laps, the stage_ms leg) or with the pose chain beside them (the timed steps: the kernel
+# that waits for the head of the launch starts inside it)
 python3 - "$(find $O/trace -name '*kernel_trace.csv' | head -1)" > $O/k_lk_by_grid.txt <<'PY'
-import csv, sys, collections
+import csv, sys, collections, bisect
+rows = list(csv.DictReader(open(sys.argv[1])))
+waits = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "k_wait_head" in r["Kernel_Name"])
+ends = [w[1] for w in waits]                # the waiting kernels do not overlap one another: sorted by start = sorted by end
 d = collections.defaultdict(list)
-for r in csv.DictReader(open(sys.argv[1])):
+for r in rows:
     if "k_lk" in r["Kernel_Name"]:
-        d[int(r.get("Grid_Size", r.get("Grid_Size_X", 0)))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-for g, v in sorted(d.items()):
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        i = bisect.bisect_right(ends, s)    # the first waiting kernel that ends after this launch starts
+        beside = i < len(waits) and waits[i][0] < e
+        d[(int(r.get("Grid_Size", r.get("Grid_Size_X", 0))), beside)].append(e - s)
+for (g, beside), v in sorted(d.items()):
     v.sort()
-    print("k_lk grid %8d (%6d keypoints): %5d launches, average %9.1f ns, median %9.1f ns, min %9.1f ns" % (g, g // 64, len(v), sum(v) / len(v), v[len(v) // 2], v[0]))
+    print("k_lk grid %8d (%6d keypoints), %-28s: %5d launches, average %9.1f ns, median %9.1f ns, min %9.1f ns"
+          % (g, g // 64, "pose chain beside it" if beside else "alone on the chip", len(v), sum(v) / len(v), v[len(v) // 2], v[0]))
 PY
 timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 > $O/bench.json
 cat $O/k_lk_pmc.txt; cat $O/k_lk_by_grid.txt; head -8 $O/kernel_stats.csv | cut -c1-160; cat $O/bench.json

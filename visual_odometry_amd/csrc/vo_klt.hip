@@ -197,13 +197,21 @@ __device__ __forceinline__ void stage_issue(float* patch, const float* __restric
         // multiple of 4 lanes (lr, lq) = (lane / NQ, lane % NQ) fill RPI whole rows per instruction from per-lane
         // source addresses that need only 4-byte alignment (scripts/ubench/glds16.hip); the address just advances.
         constexpr int NQ = C::NQ, RPI = C::RPI, NI = (C::PH + RPI - 1) / RPI;
+        // Addresses: scalar base (the patch's first pixel, advanced RPI rows per instruction on the scalar unit) + one
+        // 32-bit per-lane offset that depends on the level's pitch only -- the instruction's saddr form, written out
+        // because the builtin takes one per-lane 64-bit pointer (a 64-bit vector add per instruction, a dozen vector
+        // instructions of address set-up per patch, 17 patches a keypoint: 3 % of the kernel's vector instructions).
+        // M0 = LDS byte address of the instruction's first row (one wait state before the transfer reads it).
         if (lane < RPI * NQ) {
-            const float* g = img + ((long)(ov + lr) * pitch + (ou + 4 * lq));
+            const float* sb = img + ((long)ov * pitch + ou);
+            const unsigned voff = (unsigned)(lr * pitch + 4 * lq) * 4u;
+            const unsigned l0 = (unsigned)reinterpret_cast<uintptr_t>(patch);
 #pragma unroll
             for (int k = 0; k < NI; ++k) {
                 if ((k + 1) * RPI <= C::PH || lr < C::PH - k * RPI)
-                    __builtin_amdgcn_global_load_lds((glb_float*)g, lp + k * RPI * C::PW, 16, 0, 0);
-                g += RPI * pitch;
+                    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                                 :: "v"(voff), "s"(sb), "s"(l0), "i"(k * RPI * C::PW * 4) : "memory", "m0", "scc");
+                sb += RPI * pitch;
             }
         }
     } else {
@@ -237,6 +245,13 @@ __device__ __forceinline__ void stage(float* patch, const float* __restrict__ im
     stage_wait();
 }
 
+// -DVO_KLT_MARKS: comment lines in the assembly at the borders of the kernel's sections (scripts/klt_budget.py counts the
+// instructions between them); nothing in a normal build
+#ifdef VO_KLT_MARKS
+#define LK_MARK(name) asm volatile("; LKMARK " name ::: "memory")
+#else
+#define LK_MARK(name)
+#endif
 __device__ __forceinline__ float unif(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
 // one direction A -> B (N4).  returns flags: bit0 lost, bit1 flat at level 0.
@@ -270,6 +285,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
     const int isu = uni((int)fsu_d), isv = uni((int)fsv_d);
     const float fsu = unif((float)(su - fsu_d)), fsv = unif((float)(sv - fsv_d));
     for (int l = a.levels - 1; l >= 0; --l) {
+        LK_MARK("level");
         int nu, nv, pitch; long lo;
         level_dims(nu0, nv0, l, nu, nv, lo, pitch);
         const int lmask = (1 << l) - 1;
@@ -287,6 +303,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
         {   // ---- template set-up: E = samples on the window grown by one pixel, Sobel/8 of E.
             // Rows stream through a 3-row ring so that only 3 x (BW+2) samples are live at a time.
             const float fu = fplu, fv = fplv;
+            LK_MARK("stageA");
             stage<C>(patch, A + lo, pitch, nu, nv, iplu - ru - 1, iplv - rv - 1, lane, lr, lq);
             // E rows stream through a 3-row ring.  Separable Sobel per template row: VD = vertical
             // difference, VS = vertical 1-2-1 smoothing of the three rows, then the horizontal halves.
@@ -294,6 +311,7 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             // exactly, into G and the 2x2 inverse below).
             // opaque per-level copies: the mask words are re-extracted at each use (one v_bfe_i32) instead
             // of living in 30 registers across the kernel
+            LK_MARK("rows");
             WinMask<W41> wm = mask;
             wm.opaque();
             // Row-major lane order (lane + 1 = the block to the right): a lane samples only the BW columns that
@@ -363,11 +381,14 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             // compiler hoisted all of the rows' LDS reads in front of the transfers' barrier and sank their arithmetic
             // behind it, 54 samples live at once, and the set-up ran 2 % longer)
             asm volatile("" :: "v"(sxx), "v"(sxy), "v"(syy), "v"(ctu), "v"(ctv));
+            LK_MARK("stageB");
             stage_issue<C>(patch, B + lo, pitch, nu, nv, pou, pov, lane, lr, lq);
         }
         // sums of the x8 gradients: S = 64 G
+        LK_MARK("sums");
         float s5in[5] = {sxx, sxy, syy, ctu, ctv}, s5[5];
         wave_sums<5>(s5in, s5);
+        LK_MARK("solve");
         const float CTu = s5[3], CTv = s5[4];
         // Flat test mineig(G) / npx >= VO_MIN_EIG without the eigenvalue: with t = 64 * 2 npx VO_MIN_EIG (LKArgs::flat_thr)
         //   2 mineig(S) >= t  <=>  (2 Suu - t) + (2 Svv - t) >= 0  and  (2 Suu - t)(2 Svv - t) >= (2 Suv)^2
@@ -396,78 +417,103 @@ __device__ int lk_dir(const LKArgs& a, const float* __restrict__ A, const float*
             const float isf = __builtin_ldexpf(1.0f, -l);
             const float tlo_u = -(float)ibu, thi_u = (float)(nu0 - 1) * isf - (float)ibu;
             const float tlo_v = -(float)ibv, thi_v = (float)(nv0 - 1) * isf - (float)ibv;
-            bool staged = true, landed = false, cell = false;   // the patch sent for above: staged, not waited for yet
-            int ciu = 0, civ = 0;
+            bool staged = true, landed = false;   // the patch sent for above: staged, not waited for yet
             // sum J*(Tu,Tv) is bilinear in the sub-pixel fractions: inside one pixel cell it is the
             // interpolation of the four integer-offset correlations c[dv][du] = sum P(x+du, y+dv)*(Tu,Tv).
             // They are computed once per visited cell; an iteration inside the cell is scalar work.
             // residual inside the cell: B = k0 - fu*ka - fv*(kb + fu*kc), per gradient
             float ku0 = 0, kua = 0, kub = 0, kuc = 0, kv0 = 0, kva = 0, kvb = 0, kvc = 0;
-            for (int it = 0; it < a.max_iters; ++it) {
+            // The cell whose correlations are in hand is remembered as the FLOATS floor(tu), floor(tv) (cru, crv; 0.5: none
+            // yet -- no floor equals it), and the test an iteration makes is ONE: "still in the cell I tested last" (ctu, ctv:
+            // the same floors if that cell lies wholly inside the image, else NaN, which no floor equals -- a cell that the
+            // image border cuts is tested every time).  Outside the image and another cell are told apart behind that
+            // branch.  An iteration that stays in its cell -- three of four -- is two additions, two floors, two compares and
+            // one branch in front of the update, with no integer conversion and no trip through the scalar registers (the
+            // loop was 65 instructions a trip, half of them scalar bookkeeping around three exits; a wave's time is its
+            // instruction count, whatever unit executes them).
+            float cru = 0.5f, crv = 0.5f, ctu = __builtin_nanf(""), ctv = __builtin_nanf("");
+            int it = 0;
+            if (a.max_iters > 0) for (;;) {
+                LK_MARK("iter");
                 const float tu = fbu + du, tv = fbv + dv;
-                // (bitwise &: the four compares feed one scalar mask, no branch between them)
-                if (__builtin_amdgcn_ballot_w64(!((tu >= tlo_u) & (tu <= thi_u) & (tv >= tlo_v) & (tv <= thi_v)))) {
-                    flags |= 1;
-                    break;
-                }
-                const int iu = ibu + uni((int)floorf(tu)), iv = ibv + uni((int)floorf(tv));
-                if (!cell || iu != ciu || iv != civ) {
-                    int fi = iu - ru - pou, fj = iv - rv - pov;
-                    if (!staged || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) {
-                        pou = iu - ru - LK_M; pov = iv - rv - LK_M;
-                        stage<C>(patch, B + lo, pitch, nu, nv, pou, pov, lane, lr, lq);
-                        staged = true; landed = true;
-                        fi = LK_M; fj = LK_M;
+                const float ftu = floorf(tu), ftv = floorf(tv);
+                if (__builtin_amdgcn_ballot_w64((ftu != ctu) | (ftv != ctv))) {
+                    // N4 lost test (bitwise &: the compares feed one scalar mask, no branch between them)
+                    if (__builtin_amdgcn_ballot_w64(!((tu >= tlo_u) & (tu <= thi_u) & (tv >= tlo_v) & (tv <= thi_v)))) {
+                        flags |= 1;
+                        break;
                     }
-                    if (!landed) { stage_wait(); landed = true; }
-                    const int base = lbase + fj * PW + fi;
-                    float su00 = 0, su10 = 0, su01 = 0, su11 = 0, sv00 = 0, sv10 = 0, sv01 = 0, sv11 = 0;
+                    if (__builtin_amdgcn_ballot_w64((ftu != cru) | (ftv != crv))) {
+                        const int iu = ibu + uni((int)ftu), iv = ibv + uni((int)ftv);
+                        LK_MARK("cell");
+                        int fi = iu - ru - pou, fj = iv - rv - pov;
+                        if (!staged || fi < 0 || fi > 2 * LK_M || fj < 0 || fj > 2 * LK_M) {
+                            pou = iu - ru - LK_M; pov = iv - rv - LK_M;
+                            stage<C>(patch, B + lo, pitch, nu, nv, pou, pov, lane, lr, lq);
+                            staged = true; landed = true;
+                            fi = LK_M; fj = LK_M;
+                        }
+                        if (!landed) { stage_wait(); landed = true; }
+                        const int base = lbase + fj * PW + fi;
+                        float su00 = 0, su10 = 0, su01 = 0, su11 = 0, sv00 = 0, sv10 = 0, sv01 = 0, sv11 = 0;
 #pragma unroll
-                    for (int r = 0; r < BH + 1; ++r) {
-                        float p[BW + 1];
+                        for (int r = 0; r < BH + 1; ++r) {
+                            float p[BW + 1];
 #pragma unroll
-                        for (int c = 0; c < BW + 1; ++c) p[c] = patch[base + r * PW + c];
-                        if (r < BH) {
+                            for (int c = 0; c < BW + 1; ++c) p[c] = patch[base + r * PW + c];
+                            if (r < BH) {
 #pragma unroll
-                            for (int c = 0; c < BW; ++c) {
-                                su00 += p[c] * Tu[r][c]; su10 += p[c + 1] * Tu[r][c];
-                                sv00 += p[c] * Tv[r][c]; sv10 += p[c + 1] * Tv[r][c];
+                                for (int c = 0; c < BW; ++c) {
+                                    su00 += p[c] * Tu[r][c]; su10 += p[c + 1] * Tu[r][c];
+                                    sv00 += p[c] * Tv[r][c]; sv10 += p[c + 1] * Tv[r][c];
+                                }
+                            }
+                            if (r > 0) {
+#pragma unroll
+                                for (int c = 0; c < BW; ++c) {
+                                    su01 += p[c] * Tu[r - 1][c]; su11 += p[c + 1] * Tu[r - 1][c];
+                                    sv01 += p[c] * Tv[r - 1][c]; sv11 += p[c + 1] * Tv[r - 1][c];
+                                }
                             }
                         }
-                        if (r > 0) {
-#pragma unroll
-                            for (int c = 0; c < BW; ++c) {
-                                su01 += p[c] * Tu[r - 1][c]; su11 += p[c + 1] * Tu[r - 1][c];
-                                sv01 += p[c] * Tv[r - 1][c]; sv11 += p[c + 1] * Tv[r - 1][c];
-                            }
-                        }
+                        LK_MARK("cellsums");
+                        float c8in[8] = {su00, su10, su01, su11, sv00, sv10, sv01, sv11}, c8[8];
+                        wave_sums<8>(c8in, c8);
+                        const float cu00 = c8[0], cu10 = c8[1], cu01 = c8[2], cu11 = c8[3];
+                        const float cv00 = c8[4], cv10 = c8[5], cv01 = c8[6], cv11 = c8[7];
+                        ku0 = CTu - cu00; kua = cu10 - cu00; kub = cu01 - cu00; kuc = (cu11 - cu10) - kub;
+                        kv0 = CTv - cv00; kva = cv10 - cv00; kvb = cv01 - cv00; kvc = (cv11 - cv10) - kvb;
+                        cru = ftu; crv = ftv;
+                        ++cells;
+                        // may the next iterations skip the lost test?  Only if no position of this cell is outside
+                        const bool inside = (ftu >= tlo_u) & (ftu + 1.0f <= thi_u) & (ftv >= tlo_v) & (ftv + 1.0f <= thi_v);
+                        ctu = inside ? ftu : __builtin_nanf(""); ctv = ftv;
                     }
-                    float c8in[8] = {su00, su10, su01, su11, sv00, sv10, sv01, sv11}, c8[8];
-                    wave_sums<8>(c8in, c8);
-                    const float cu00 = c8[0], cu10 = c8[1], cu01 = c8[2], cu11 = c8[3];
-                    const float cv00 = c8[4], cv10 = c8[5], cv01 = c8[6], cv11 = c8[7];
-                    ku0 = CTu - cu00; kua = cu10 - cu00; kub = cu01 - cu00; kuc = (cu11 - cu10) - kub;
-                    kv0 = CTv - cv00; kva = cv10 - cv00; kvb = cv01 - cv00; kvc = (cv11 - cv10) - kvb;
-                    cell = true; ciu = iu; civ = iv;
-                    ++cells;
                 }
+                LK_MARK("update");
                 const float fu = __builtin_amdgcn_fractf(tu), fv = __builtin_amdgcn_fractf(tv);   // = tu - floor(tu)
                 const float Bu = (ku0 - fu * kua) - fv * (kub + fu * kuc);
                 const float Bv = (kv0 - fu * kva) - fv * (kvb + fu * kvc);
-                ++iters;
                 const float ddu = fmaf(iuu, Bu, iuv * Bv);
                 const float ddv = fmaf(iuv, Bu, ivv * Bv);
                 du += ddu; dv += ddv;
-                if (__builtin_amdgcn_ballot_w64(fmaf(ddu, ddu, ddv * ddv) < a.eps2)) break;
+                ++it;
+                // one exit test for "converged" and "out of iterations": the last iteration compares with +inf (a step that is
+                // infinite or NaN there goes round once more and leaves through the lost test, as it would a level later)
+                const float lim = it >= a.max_iters ? __builtin_inff() : a.eps2;
+                if (__builtin_amdgcn_ballot_w64(fmaf(ddu, ddu, ddv * ddv) < lim)) break;
             }
+            iters += it;   // updates executed (an iteration that ends in the lost test is not one)
             if (l == 0) { staged0 = staged; pou0 = pou; pov0 = pov; }
         }
+        LK_MARK("levelend");
         if (flags & 1) break;
         if (l > 0) { gu = 2.0f * (gu + du); gv = 2.0f * (gv + dv); }
         else { gu = gu + du; gv = gv + dv; }
     }
     // a search patch sent ahead that nothing waited for (a flat level, a point lost at its first iteration) must have
     // landed before the LDS is used again -- by this wave, or by the workgroup that gets the LDS after this one ends
+    LK_MARK("dirend");
     stage_wait();
     qu = su + (double)gu; qv = sv + (double)gv;
     if (!(flags & 1)) {
