@@ -340,33 +340,56 @@ __global__ __launch_bounds__(DT_BLOCK) void k_detect(const double* __restrict__ 
     atomicAdd(&g.count[grid_cell1(fv, g.inv_cs, g.gv) * g.gu + grid_cell1(fu, g.inv_cs, g.gu)], 1);
 }
 
-// exclusive scan of a table of counts by ONE wave, total -> *m0 (clamped to cap): 256 entries a step (four per lane in
-// one 16-byte load, the next step's load in flight while this step's wave scan runs), the running total carried in a
-// scalar.  ~30 steps for a KITTI frame's 7.3k blocks or 7.7k grid cells.
+// inclusive scan over the wave's 64 lanes without the LDS: four shifts inside the rows of 16 lanes, then lane 15 of every
+// odd row's predecessor and lane 31 into the upper half (DPP row_shr / row_bcast; a lane without a source adds the 0 it
+// is given as the old value) -- six dependent vector adds instead of six trips through ds_bpermute
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_or_zero(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, ROWS, 0xf, false); }
+__device__ __forceinline__ int wave_scan_incl(int x) {
+    x += dpp_or_zero<0x111, 0xf>(x);   // row_shr:1
+    x += dpp_or_zero<0x112, 0xf>(x);   // row_shr:2
+    x += dpp_or_zero<0x114, 0xf>(x);   // row_shr:4
+    x += dpp_or_zero<0x118, 0xf>(x);   // row_shr:8
+    x += dpp_or_zero<0x142, 0xa>(x);   // row_bcast:15 into rows 1 and 3
+    x += dpp_or_zero<0x143, 0xc>(x);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+// exclusive scan of a table of counts by ONE wave, total -> *m0 (clamped to cap): 512 entries a step (eight per lane in
+// two 16-byte loads, the next step's loads in flight while this step's wave scan runs), the running total carried in a
+// scalar.  15 steps for a KITTI frame's 7.3k blocks or 7.7k grid cells, ~30 instructions each: the launch sits in the
+// image-only half that runs beside a tracking launch, where every instruction of a lone wave waits its turn.
 __global__ __launch_bounds__(64) void k_scan_counts(const int32_t* __restrict__ counts, int n, int32_t* offs,
                                                      int32_t* m0, int cap) {
     const int lane = threadIdx.x;
-    auto load4 = [&](int i, int (&c)[4]) {
-        if (i + 3 < n) { const int4 v = *reinterpret_cast<const int4*>(counts + i); c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w; }
-        else for (int k = 0; k < 4; ++k) c[k] = i + k < n ? counts[i + k] : 0;
+    auto load8 = [&](int i, int (&c)[8]) {
+        if (i + 7 < n) {
+            const int4 v = *reinterpret_cast<const int4*>(counts + i), w = *reinterpret_cast<const int4*>(counts + i + 4);
+            c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w; c[4] = w.x; c[5] = w.y; c[6] = w.z; c[7] = w.w;
+        } else for (int k = 0; k < 8; ++k) c[k] = i + k < n ? counts[i + k] : 0;
     };
     int carry = 0;
-    int nxt[4];
-    load4(4 * lane, nxt);
-    for (int base = 0; base < n; base += 256) {
-        const int i = base + 4 * lane;
-        const int c0 = nxt[0], c1 = nxt[1], c2 = nxt[2], c3 = nxt[3];
-        if (base + 256 < n) load4(i + 256, nxt);
-        const int s = (c0 + c1) + (c2 + c3);
-        int inc = s;
+    int nxt[8];
+    load8(8 * lane, nxt);
+    for (int base = 0; base < n; base += 512) {
+        const int i = base + 8 * lane;
+        int c[8];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        for (int k = 0; k < 8; ++k) c[k] = nxt[k];
+        if (base + 512 < n) load8(i + 512, nxt);
+        int e[8];   // exclusive prefix inside the lane's eight
+        e[0] = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) e[k] = e[k - 1] + c[k - 1];
+        const int s = e[7] + c[7];
+        const int inc = wave_scan_incl(s);
         const int run = carry + inc - s;
-        if (i + 3 < n) *reinterpret_cast<int4*>(offs + i) = make_int4(run, run + c0, run + c0 + c1, run + c0 + c1 + c2);
-        else {
-            if (i < n) offs[i] = run;
-            if (i + 1 < n) offs[i + 1] = run + c0;
-            if (i + 2 < n) offs[i + 2] = run + c0 + c1;
+        if (i + 7 < n) {
+            *reinterpret_cast<int4*>(offs + i) = make_int4(run, run + e[1], run + e[2], run + e[3]);
+            *reinterpret_cast<int4*>(offs + i + 4) = make_int4(run + e[4], run + e[5], run + e[6], run + e[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (i + k < n) offs[i + k] = run + e[k];
         }
         carry += __builtin_amdgcn_readlane(inc, 63);
     }
