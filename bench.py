@@ -186,27 +186,11 @@ def frame_loop_leg(ctx, with_cpu, n_frames=24):
     # processFrame rather than for five stages on canned inputs.  MinDistance is 1.5 px here: at the reference's 7 px a
     # KITTI frame has no room for 50k points (discs of radius 7 around them cover it 16 times over), so no new candidate
     # would ever pass the filter and the candidate set would run dry after maxTemporalRecall frames.
-    rng = np.random.default_rng(5)
-    n_l = 25000
-    lu = rng.uniform(25, 1241 - 26, n_l); lv = rng.uniform(25, 376 - 26, n_l)
-    st5 = modules._new_state()
-    st5.keypoints = np.stack([lu, lv], 1); st5.landmarks = lift(lu, lv); st5.reproError = np.zeros(n_l)
     # ... and 25 000 candidates first seen 1 .. 10 frames before frame 0 (poses extrapolated backwards along the track, first
     # keypoints = their projections there): with the angular threshold at 6 degrees (0.57 degrees of parallax a frame at
     # this depth) about 2 500 of them become promotable every frame, each replacing the worst landmark at the cap
-    n_c = 25000
-    cu0 = rng.uniform(25, 1241 - 26, n_c); cv0 = rng.uniform(25, 376 - 26, n_c)
-    Xc = lift(cu0, cv0)
-    age = rng.integers(1, 11, n_c)
-    step, yaw = np.array([0.2, 0.0, 0.15]), 0.15
-    first_xy = np.zeros((n_c, 2)); first_pose = np.zeros((n_c, 4, 3))
-    for a_ in range(1, 11):
-        sel = age == a_
-        R_, C_ = synth.rot_y(-yaw * a_), -step * a_
-        first_pose[sel] = synth.pose43(R_, C_)
-        first_xy[sel] = synth.project(K, R_, C_, Xc[sel])[0]
-    st5.candidate_keypoints = np.stack([cu0, cv0], 1); st5.candidate_first_keypoints = first_xy
-    st5.candidate_first_poses = first_pose; st5.candidate_time_indxs = -age.astype(np.int64)
+    n_l = n_c = 25000
+    st5 = synth.stress_state(K, lift, modules._new_state, n_l, n_c)
     loop5 = FrameLoop(K, frames[0].shape, maxNumLandmarks=n_l, maxCandidates=n_c, CandidatesToKeep=5000, MinDistance=1.5,
                       angularThreshold=6.0, maxTemporalRecall=16, ctx=ctx)
     best5, med5, (pose5, status5, info5) = passes(loop5, st5, True, depth=2)

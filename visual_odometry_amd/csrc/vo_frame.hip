@@ -64,6 +64,80 @@ __global__ __launch_bounds__(1024) void k_compact2(OpA a, int na, int32_t* count
     if (threadIdx.x == 0) *count_b_clamped = *count_b < cap_b ? *count_b : cap_b;
 }
 
+// ---- the same ordered compactions for states of tens of thousands of entries (the stress size: 25k landmarks, 25k
+// candidates), where one block walking 1024 elements a step is 25-50 steps of two barriers each (k_tracked 105-146 us,
+// k_pose_tail 70, k_compact2 84 in the trace of a 25k + 25k frame) and a 1024-thread block beside a tracking launch
+// waits for a compute unit to itself.  One-wave workgroups of CW_BLOCK elements: a wave counts its kept elements row by
+// row (ballots), PUBLISHES the count in a word of its own (launch epoch << 32 | count, an agent-scope atomic store:
+// written through), adds up the counts of the workgroups in front of it (every lane polls some of them -- nobody waits
+// for a sum, only for counts that their owners publish before they wait for anything themselves, and workgroups are
+// dispatched in index order: the ones in front are resident or done) and moves its elements.  The last workgroup
+// writes the total.  The epoch (a host counter, one per launch) tells this launch's words from an earlier one's, so the
+// words are never cleared; a poll gives up after CW_SPINS looks, so the grid drains whatever happens.
+constexpr int CW_EPL = 8, CW_BLOCK = 64 * CW_EPL, CW_MAX_BLOCKS = 256, CW_SITES = 8, CW_SPINS = 1 << 20;
+struct Chain { unsigned long long* w; unsigned epoch; };
+__device__ __forceinline__ int wave_sum_i(int x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+__device__ __forceinline__ int chain_exclusive(const Chain& c, int b, int tot) {
+    const int lane = threadIdx.x;
+    if (lane == 0)
+        __hip_atomic_store(&c.w[b], ((unsigned long long)c.epoch << 32) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int sum = 0;
+    for (int j = lane; j < b; j += 64) {
+        unsigned long long v = 0;
+        for (int spin = 0; spin < CW_SPINS; ++spin) {
+            v = __hip_atomic_load(&c.w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == c.epoch) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        sum += (int)(unsigned)v;
+    }
+    return wave_sum_i(sum);
+}
+// rows of 64 consecutive elements: element i0 + 64 k + lane; keep(k) says whether the lane's element of row k stays.
+// Returns the lane's output positions (pos[k], valid where keep) through `pos`, the workgroup's count in *tot and its
+// exclusive base.
+template <class Keep>
+__device__ __forceinline__ int wave_positions(const Chain& ch, Keep keep, int (&pos)[CW_EPL], unsigned& fbits, int* tot) {
+    int run = 0;
+    fbits = 0;
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k) {
+        const bool f = keep(k);
+        const unsigned long long bal = __ballot(f);
+        pos[k] = run + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        run += __popcll(bal);
+        fbits |= (f ? 1u : 0u) << k;
+    }
+    *tot = run;
+    return chain_exclusive(ch, blockIdx.x, run);
+}
+template <class Op>
+__device__ __forceinline__ void compact_wave(const Op& op, int n, const Chain& ch, int32_t* count, int32_t* count_clamped = nullptr, int cap = 0) {
+    const int i0 = blockIdx.x * CW_BLOCK + (int)threadIdx.x;
+    int pos[CW_EPL], tot;
+    unsigned fbits;
+    const int base = wave_positions(ch, [&](int k) { const int i = i0 + 64 * k; return i < n && op.flag(i); }, pos, fbits, &tot);
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k)
+        if ((fbits >> k) & 1u) op.move(i0 + 64 * k, base + pos[k]);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        if (count) *count = base + tot;
+        if (count_clamped) *count_clamped = base + tot < cap ? base + tot : cap;
+    }
+}
+inline int cw_blocks(int n) { return (n + CW_BLOCK - 1) / CW_BLOCK; }
+// two independent compactions in one launch: blockIdx.y = 0 does A, 1 does B (k_compact2 for large states)
+template <class OpA, class OpB>
+__global__ __launch_bounds__(64) void k_compact2_w(OpA a, int na, int32_t* count_a, const int32_t* na_dev, Chain cha, OpB b, int nb,
+                                                   int32_t* count_b, int32_t* count_b_clamped, int cap_b, Chain chb) {
+    if (blockIdx.y == 0) compact_wave(a, na_dev ? min(na, *na_dev) : na, cha, count_a);
+    else compact_wave(b, nb, chb, count_b, count_b_clamped, cap_b);
+}
+
 // landmarks whose keypoint tracked validly (:280-281): (q, L) -> (vk, vl), pitch = capL
 struct TrackedOp {
     const uint8_t* valid; const double *qu, *qv, *L; int capL; double *vk, *vl;
@@ -145,6 +219,59 @@ __global__ __launch_bounds__(1024) void k_pose_tail(PoseTailArgs a) {
     if (tid == 0) *a.count = base;
 }
 
+// the same for large states: one-wave workgroups (every one folds the record's pose itself: twelve values)
+__global__ __launch_bounds__(64) void k_pose_tail_w(PoseTailArgs a, Chain ch) {
+    __shared__ double s_pose[12], s_P[12];
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x;
+    int32_t* info = (int32_t*)(a.rsout + 12);
+    const int Md = min(a.capL, *a.M_dev);
+    if (tid < 12) {
+        const double* out = a.rsout;
+        const int c = tid - 9;
+        const double p = tid < 9 ? out[tid] : -((out[c] * out[9] + out[3 + c] * out[10]) + out[6 + c] * out[11]);
+        if (blockIdx.x == 0) a.pose_now[tid] = p;
+        s_pose[tid] = p;
+        s_P[tid] = proj_elem(out, a.K, tid >> 2, tid & 3);
+    }
+    __syncthreads();
+    const bool solved = info[0] == 0;
+    double P[12], K[9], cam[12];
+    for (int k = 0; k < 12; ++k) P[k] = s_P[k];
+    for (int k = 0; k < 9; ++k) K[k] = a.K[k];
+    camera_matrix(s_pose, K, cam);
+    const int i0 = blockIdx.x * CW_BLOCK + tid;
+    int n_in = 0;
+    int pos[CW_EPL], tot;
+    unsigned fbits;
+    const int base = wave_positions(ch, [&](int k) {
+        const int i = i0 + 64 * k;
+        bool in = false, f = false;
+        if (i < Md) {
+            const double Xi[3] = {a.vl[i], a.vl[a.capL + i], a.vl[2 * a.capL + i]};
+            const double x = a.vk[i], y = a.vk[a.capL + i];
+            if (solved) {
+                const ProjT p = proj_terms(P, Xi[0], Xi[1], Xi[2], x, y);
+                in = p.ez < a.thr2 * p.z2;
+            }
+            double u, v, w;
+            project(cam, Xi, u, v, w);
+            const double du = x - u, dv = y - v;
+            const double e = sqrt(du * du + dv * dv);
+            a.err[i] = e;
+            f = e < a.kop.thr;
+        }
+        if (i < a.capL) a.inl[i] = in ? 1 : 0;
+        n_in += __popcll(__ballot(in));
+        return f;
+    }, pos, fbits, &tot);
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k)
+        if ((fbits >> k) & 1u) a.kop.move(i0 + 64 * k, base + pos[k]);
+    if (tid == 0 && n_in) atomicAdd(&info[4], n_in);
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *a.count = base + tot;
+}
+
 // :106-113, :130: 0 drop, 1 promote (angle large), 2 keep as candidate (angle small, young enough)
 struct ClassifyArgs {
     const uint8_t *tracked, *ok; const double *rep, *ang; const int32_t* ctime; double max_rep, ang_thr; int recall;
@@ -187,6 +314,19 @@ __global__ __launch_bounds__(1024) void k_tracked(int32_t* counts, uint8_t* aliv
     for (int i = threadIdx.x; i < pw; i += 1024) alive[i] = 0;
     __syncthreads();                                     // counts[6] is cleared before the compaction writes it
     compact_block(top, capL, counts + 6, nL_dev, s_w);
+}
+
+// the same for large states: one-wave workgroups; every counter but counts[6] is cleared by the first workgroup, counts[6]
+// is written by the last (no word has two writers)
+__global__ __launch_bounds__(64) void k_tracked_w(int32_t* counts, uint8_t* alive, int pw, TrackedOp top, int capL, const int32_t* nL_dev, Chain ch) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid < 16 && tid != 6) counts[tid] = 0;
+    // tombstones: four bytes a lane, pw is a multiple of ... anything: the tail byte by byte
+    for (int i = 4 * ((int)blockIdx.x * 64 + tid); i < pw; i += 4 * 64 * (int)gridDim.x) {
+        if (i + 3 < pw) *reinterpret_cast<uint32_t*>(alive + i) = 0u;
+        else for (int k = i; k < pw; ++k) alive[k] = 0;
+    }
+    compact_wave(top, min(capL, *nL_dev), ch, counts + 6);
 }
 
 // The order-dependent merge of :87-142 over the promotable candidates, in candidate order: at the landmark
@@ -454,6 +594,42 @@ __global__ __launch_bounds__(1024) void k_merge_write(MergeWideArgs w) {
     if (tid == 0) *a.n_promoted = prom;
 }
 
+// k_merge_list and k_merge_write for large states: one-wave workgroups (compact_wave's scheme)
+__global__ __launch_bounds__(64) void k_merge_list_w(MergeWideArgs w, Chain ch) {
+    const MergeArgs& a = w.m;
+    const int tid = threadIdx.x;
+    const int n0 = *a.n0, nC = *a.nC_dev;
+    for (int e = (int)blockIdx.x * 64 + tid; e < n0; e += 64 * (int)gridDim.x) w.pool[e] = a.wrep[e];
+    const int i0 = blockIdx.x * CW_BLOCK + tid;
+    int pos[CW_EPL], tot;
+    unsigned fbits;
+    const int base = wave_positions(ch, [&](int k) { const int i = i0 + 64 * k; return i < nC && a.c.cls(i) == 1; }, pos, fbits, &tot);
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k)
+        if ((fbits >> k) & 1u) { const int i = i0 + 64 * k, d = base + pos[k]; a.plist[d] = i; w.pool[n0 + d] = a.crep[i]; }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *w.np_out = base + tot;
+}
+__global__ __launch_bounds__(64) void k_merge_write_w(MergeWideArgs w, Chain ch) {
+    const MergeArgs& a = w.m;
+    const int tid = threadIdx.x;
+    const int n0 = *a.n0, np = *w.np_out;
+    for (int i = (int)blockIdx.x * 64 + tid; i < n0; i += 64 * (int)gridDim.x) a.alive[i] = w.surv[i];
+    const int j0 = blockIdx.x * CW_BLOCK + tid;
+    int pos[CW_EPL], tot;
+    unsigned fbits;
+    const int base = wave_positions(ch, [&](int k) { const int j = j0 + 64 * k; return j < np && w.acc[n0 + j] != 0; }, pos, fbits, &tot);
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k)
+        if ((fbits >> k) & 1u) {
+            const int j = j0 + 64 * k, i = a.plist[j], d = n0 + base + pos[k];
+            a.wL[d] = a.X[i]; a.wL[a.PW + d] = a.X[a.capC + i]; a.wL[2 * a.PW + d] = a.X[2 * a.capC + i];
+            a.wkp[d] = a.cq[i]; a.wkp[a.PW + d] = a.cq[a.capC + i];
+            a.wrep[d] = w.pool[n0 + j];
+            a.alive[d] = w.surv[n0 + j];
+        }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *a.n_promoted = base + tot;
+}
+
 // :338-345 append the new candidates: first keypoint = keypoint, first pose = this frame's, time -1
 // ... and, last kernel of a frame, gather what the host reads back into one record (one copy instead of three):
 // the pose step's record (16 doubles), the pose (12), the counters (16 int32)
@@ -527,6 +703,8 @@ struct vo_frame_state {
     int32_t *pos, *plist, *counts2[2], *slin;   // counts2: a frame's counters, by frame parity
     double* skey; int32_t *sidx, *sbefore; int sort_padded;   // the wide merge's sort: two key / index buffers, the `before` counts
     int32_t* sizes;                         // device: {landmarks, candidates} of state s (k_append_new / set_state)
+    unsigned long long* chain;              // the wide compactions' count words: CW_SITES call sites x CW_MAX_BLOCKS (zeroed once)
+    unsigned chain_epoch = 0;               // one per wide compaction launched
     int32_t* h_counts;                      // pinned
     double* h_rec;                          // pinned: VO_FRAME_MAX_PENDING records of 40 doubles (ransac record 16, pose 12, counters)
     // frames submitted and not collected yet, oldest first
@@ -577,6 +755,7 @@ void carve(vo_frame_state* st, char* base, size_t* total) {
     st->sbefore = b.take<int32_t>((size_t)st->sort_padded);
     st->pos = b.take<int32_t>(pw); st->plist = b.take<int32_t>(cc); st->counts2[0] = b.take<int32_t>(16); st->counts2[1] = b.take<int32_t>(16);
     st->sizes = b.take<int32_t>(16);
+    st->chain = b.take<unsigned long long>((size_t)CW_SITES * CW_MAX_BLOCKS);
     *total = b.off + 256;
 }
 int copy_image(vo_ctx* ctx, vo_frame_state* st, int slot, const uint8_t* img, int on_device, hipStream_t stream = nullptr) {
@@ -885,6 +1064,12 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         ctx->stream = sl; ctx->in_lane = true;           // the launchers below enqueue on ctx->stream
     }
     auto leave_lane = [&]() { ctx->stream = sm; ctx->in_lane = false; };
+    // large states: the ordered compactions as launches of one-wave workgroups (compact_wave) instead of one block each
+    const bool wide = (cl > 2048 || cc > 2048) && cw_blocks(pw) <= CW_MAX_BLOCKS && !getenv("VO_FRAME_NARROW");
+    auto chain = [&](int site) {
+        if (++st->chain_epoch == 0) ++st->chain_epoch;     // 0 is what a never-written word holds
+        return Chain{st->chain + (size_t)site * CW_MAX_BLOCKS, st->chain_epoch};
+    };
     auto stamp = [&](hipStream_t q, int id) {
         if (st->h_stamps && frame_no < STAMP_FRAMES && ((st->stamp_mask >> id) & 1)) hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, q, st->h_stamps + (size_t)frame_no * STAMP_N + id);
     };
@@ -897,7 +1082,8 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     stamp(sl, 1);
     {   // (the frame's counters and tombstones are cleared by the same launch)
         TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
-        hipLaunchKernelGGL(k_tracked, dim3(1), dim3(1024), 0, sl, counts, st->alive, pw, top, cl, st->sizes + 0);
+        if (wide) hipLaunchKernelGGL(k_tracked_w, dim3(cw_blocks(cl)), dim3(64), 0, sl, counts, st->alive, pw, top, cl, st->sizes + 0, chain(0));
+        else hipLaunchKernelGGL(k_tracked, dim3(1), dim3(1024), 0, sl, counts, st->alive, pw, top, cl, st->sizes + 0);
     }
     stamp(sl, 2);
     // [2] :285-289 pose (fewer than 4 tracked points: k_best gives status 1 and the identity, as the toolbox function errors out)
@@ -916,7 +1102,8 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         pt.thr2 = ro.max_reproj_err * ro.max_reproj_err; pt.rsout = rsout; pt.inl = st->inl; pt.pose_now = pose_now; pt.err = st->err;
         pt.kop = KeptOp{st->err, o.max_reproj_err, st->vk, st->vl, cl, pw, st->wkp, st->wL, st->wrep, st->alive};
         pt.count = counts + 7;
-        hipLaunchKernelGGL(k_pose_tail, dim3(1), dim3(1024), 0, sl, pt);
+        if (wide) hipLaunchKernelGGL(k_pose_tail_w, dim3(cw_blocks(cl)), dim3(64), 0, sl, pt, chain(1));
+        else hipLaunchKernelGGL(k_pose_tail, dim3(1), dim3(1024), 0, sl, pt);
     }
     stamp(sl, 4);
     if (sl != sm) {
@@ -963,15 +1150,23 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
             const int padded = st->sort_padded;
             MergeWideArgs mw = {m, st->pin, (uint8_t*)st->pos, (uint8_t*)st->pos + pw, counts + 9,
                                 {st->skey, st->skey + padded}, {st->sidx, st->sidx + padded}, st->sbefore, padded};
-            hipLaunchKernelGGL(k_merge_list, dim3(1), dim3(1024), 0, sm, mw);
+            if (wide) hipLaunchKernelGGL(k_merge_list_w, dim3(cw_blocks(std::max(cc, cl))), dim3(64), 0, sm, mw, chain(2));
+            else hipLaunchKernelGGL(k_merge_list, dim3(1), dim3(1024), 0, sm, mw);
             hipLaunchKernelGGL(k_sort_tiles, dim3(padded / SORT_TILE), dim3(1024), 0, sm, mw);
             int from = 0;
             for (int L = SORT_TILE; L < padded; L <<= 1, from ^= 1)
                 hipLaunchKernelGGL(k_sort_merge, dim3(blocks(padded)), dim3(256), 0, sm, mw, L, from);
             hipLaunchKernelGGL(k_sort_ranks, dim3(blocks(pw)), dim3(256), 0, sm, mw, from);
-            hipLaunchKernelGGL(k_merge_write, dim3(1), dim3(1024), 0, sm, mw);
-            hipLaunchKernelGGL((k_compact2<CandOp, LandmarkOp>), dim3(2), dim3(1024), 0, sm, cop, cc, counts + 1, st->sizes + 1, lop, pw, counts + 0,
-                               st->sizes + 0, cl);
+            if (wide) {
+                hipLaunchKernelGGL(k_merge_write_w, dim3(cw_blocks(std::max(cc, cl))), dim3(64), 0, sm, mw, chain(3));
+                const Chain cha = chain(4), chb = chain(5);
+                hipLaunchKernelGGL((k_compact2_w<CandOp, LandmarkOp>), dim3(cw_blocks(std::max(cc, pw)), 2), dim3(64), 0, sm, cop, cc, counts + 1,
+                                   st->sizes + 1, cha, lop, pw, counts + 0, st->sizes + 0, cl, chb);
+            } else {
+                hipLaunchKernelGGL(k_merge_write, dim3(1), dim3(1024), 0, sm, mw);
+                hipLaunchKernelGGL((k_compact2<CandOp, LandmarkOp>), dim3(2), dim3(1024), 0, sm, cop, cc, counts + 1, st->sizes + 1, lop, pw, counts + 0,
+                                   st->sizes + 0, cl);
+            }
         }
     }
     stamp(sm, 8);
@@ -992,7 +1187,9 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     }
     stamp(sm, 10);
     const int ps = (st->pend_head + st->pend_count) % VO_FRAME_MAX_PENDING;
-    hipLaunchKernelGGL(k_append_new, dim3(blocks(std::max(o.sel.keep, 1))), dim3(256), 0, sm, counts, cl, cc, st->su, st->sv, slot,
+    // (one-wave workgroups: the launch may find the next frame's landmark track on every compute unit already, and a
+    // four-wave workgroup then waits for four free slots on one of them -- 0.28 ms in the trace of a 25k + 25k frame)
+    hipLaunchKernelGGL(k_append_new, dim3(blocks(std::max(o.sel.keep, 36), 64)), dim3(64), 0, sm, counts, cl, cc, st->su, st->sv, slot,
                        st->cu[n], st->cf[n], st->cpose[n], st->ctime[n], rsout, pose_now, st->h_rec + 40 * (size_t)ps, st->sizes);
     // the frame's record into the next pinned slot; whoever collects the frame waits for the slot's event only
     // (enqueued before the look-ahead's dozen launches: the record is not held up behind host work it does not need)

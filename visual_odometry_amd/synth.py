@@ -211,3 +211,27 @@ def relief_sequence(n_frames, K, nv=240, nu=320, seed=91, depth=12.0, relief=2.5
         return np.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z], 1)
 
     return frames, poses, lift
+
+
+def stress_state(K, lift, new_state, n_l=25000, n_c=25000, nv=376, nu=1241, seed=5, step=(0.2, 0.0, 0.15), yaw=0.15, max_age=10):
+    """The frame loop's state at the stress size (SURVEY 8d stress variant; bench.py `frame_loop.at_50k_keypoints`):
+    n_l landmarks on the plane of plane_sequence (lift: frame-0 pixels -> landmarks), and n_c candidates first seen
+    1 .. max_age frames before frame 0 -- poses extrapolated backwards along the track, first keypoints = their
+    projections there.  new_state: the constructor of the state record (modules._new_state)."""
+    rng = np.random.default_rng(seed)
+    lu = rng.uniform(25, nu - 26, n_l); lv = rng.uniform(25, nv - 26, n_l)
+    st = new_state()
+    st.keypoints = np.stack([lu, lv], 1); st.landmarks = lift(lu, lv); st.reproError = np.zeros(n_l)
+    cu0 = rng.uniform(25, nu - 26, n_c); cv0 = rng.uniform(25, nv - 26, n_c)
+    Xc = lift(cu0, cv0)
+    age = rng.integers(1, max_age + 1, n_c)
+    step = np.asarray(step, dtype=np.float64)
+    first_xy = np.zeros((n_c, 2)); first_pose = np.zeros((n_c, 4, 3))
+    for a_ in range(1, max_age + 1):
+        sel = age == a_
+        R_, C_ = rot_y(-yaw * a_), -step * a_
+        first_pose[sel] = pose43(R_, C_)
+        first_xy[sel] = project(K, R_, C_, Xc[sel])[0]
+    st.candidate_keypoints = np.stack([cu0, cv0], 1); st.candidate_first_keypoints = first_xy
+    st.candidate_first_poses = first_pose; st.candidate_time_indxs = -age.astype(np.int64)
+    return st
