@@ -185,26 +185,38 @@ def frame_loop_leg(ctx, with_cpu, n_frames=24):
     # 25 000 candidates, up to 5 000 new candidates a frame -- what "50k keypoints per frame" means for the state chain of
     # processFrame rather than for five stages on canned inputs.  MinDistance is 1.5 px here: at the reference's 7 px a
     # KITTI frame has no room for 50k points (discs of radius 7 around them cover it 16 times over), so no new candidate
-    # would ever pass the filter and the candidate set would run dry after maxTemporalRecall frames.
-    # ... and 25 000 candidates first seen 1 .. 10 frames before frame 0 (poses extrapolated backwards along the track, first
-    # keypoints = their projections there): with the angular threshold at 6 degrees (0.57 degrees of parallax a frame at
-    # this depth) about 2 500 of them become promotable every frame, each replacing the worst landmark at the cap
+    # would ever pass the filter.  The candidates are seeded: first seen 1 .. 20 frames before frame 0 (poses extrapolated
+    # backwards along the track, first keypoints = their projections there); with the angular threshold at 12 degrees
+    # (0.57 degrees of parallax a frame at this depth) a cohort of 1 250 becomes promotable every frame, each promotion
+    # replacing the worst landmark at the cap, and the detector finds 500 - 1 800 new corners a frame (a 1241 x 376 frame
+    # holds ~13k corners of this detector: the seeded 50k settle towards what the scene can feed, see keypoints_mean).
     n_l = n_c = 25000
-    st5 = synth.stress_state(K, lift, modules._new_state, n_l, n_c)
+    st5 = synth.stress_state(K, lift, modules._new_state, n_l, n_c, max_age=20)
     loop5 = FrameLoop(K, frames[0].shape, maxNumLandmarks=n_l, maxCandidates=n_c, CandidatesToKeep=5000, MinDistance=1.5,
-                      angularThreshold=6.0, maxTemporalRecall=16, ctx=ctx)
+                      angularThreshold=12.0, maxTemporalRecall=24, ctx=ctx)
     best5, med5, (pose5, status5, info5) = passes(loop5, st5, True, depth=2)
+    loop5.set_state(st5, dev[0])                           # one more pass, a call per frame, for the counts frame by frame
+    held = []
+    for k in range(1, n_frames):
+        _, _, inf = loop5.processFrame(dev[k], dev[k + 1] if k + 1 < n_frames else None)
+        held.append((inf["n_landmarks"], inf["n_candidates"], inf["n_promoted"], inf["n_new"]))
     loop5.close()
+    held = np.array(held, dtype=np.float64)
+    # keypoints a frame tracks = the state it starts from: landmarks + candidates after the frame before (50 000 for frame 1)
+    tracked = np.concatenate([[n_l + n_c], held[:-1, 0] + held[:-1, 1]])
     out["at_50k_keypoints"] = {"ms_per_frame": 1e3 * best5 / (n_frames - 1), "ms_per_frame_median": 1e3 * med5 / (n_frames - 1),
-                               "frames_per_s": (n_frames - 1) / med5, "final_landmarks": info5["n_landmarks"],
-                               "final_candidates": info5["n_candidates"], "tracked_last_frame": info5["n_tracked"],
-                               "promoted_last_frame": info5["n_promoted"], "new_last_frame": info5["n_new"], "pose_status": status5,
+                               "frames_per_s": (n_frames - 1) / med5, "keypoints_mean": float(tracked.mean()),
+                               "keypoints_first_frame": int(tracked[0]), "keypoints_last_frame": int(tracked[-1]),
+                               "promoted_mean": float(held[:, 2].mean()), "new_mean": float(held[:, 3].mean()),
+                               "final_landmarks": info5["n_landmarks"], "final_candidates": info5["n_candidates"],
+                               "pose_status": status5,
                                "workload": "vo_frame_submit / _collect, two frames in flight: maxNumLandmarks 25000 (the state starts "
-                                           "at the cap) + 25000 candidates of ages 1..10 frames (maxCandidates 25000), angular "
-                                           "threshold 6 degrees and maxTemporalRecall 16 (about 2500 candidates become promotable a "
-                                           "frame), CandidatesToKeep 5000, MinDistance 1.5 px (at 7 px a KITTI frame has no room for "
-                                           "50k points), everything else as above; the merge is the sort-based form; "
-                                           "frames_per_s from the median pass"}
+                                           "at the cap) + 25000 candidates of ages 1..20 frames (maxCandidates 25000), angular "
+                                           "threshold 12 degrees and maxTemporalRecall 24 (a cohort of 1250 candidates becomes "
+                                           "promotable a frame), CandidatesToKeep 5000, MinDistance 1.5 px (at 7 px a KITTI frame has "
+                                           "no room for 50k points), everything else as above; the merge is the sort-based form, the "
+                                           "compactions the one-wave form; keypoints_mean = keypoints tracked per frame over the "
+                                           "pass (the scene feeds fewer new corners than expire); frames_per_s from the median pass"}
     if with_cpu:                                          # cpu_baseline of this leg: the oracle's restatement
         from oracle import vo_frame
         threads = min(16, os.cpu_count() or 1)

@@ -1,23 +1,31 @@
 """GPU-only driver for the device-resident frame loop at the stress size (bench.py `frame_loop.at_50k_keypoints`):
-25 000 landmarks at the cap + 25 000 seeded candidates, 5000 new candidates a frame.
-    python scripts/frame_stress.py [n_frames] [passes] [frames in flight]"""
-import sys, time
+25 000 landmarks at the cap + 25 000 seeded candidates, up to 5000 new candidates a frame.
+    python scripts/frame_stress.py [--frames 24] [--passes 5] [--depth 2] [--sigma 2.0] [--angle 12] [--recall 24] [--max-age 20] [--counts]"""
+import argparse, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 import torch
 from visual_odometry_amd import _lib, modules, synth
 from visual_odometry_amd.frame import FrameLoop
-n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-depth = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=24)
+ap.add_argument("--passes", type=int, default=5)
+ap.add_argument("--depth", type=int, default=2, help="frames in flight")
+ap.add_argument("--sigma", type=float, default=2.0, help="blur of the plane's texture")
+ap.add_argument("--angle", type=float, default=12.0, help="angularThreshold, degrees")
+ap.add_argument("--recall", type=int, default=24, help="maxTemporalRecall")
+ap.add_argument("--max-age", type=int, default=20, help="the seeded candidates were first seen 1 .. max-age frames ago")
+ap.add_argument("--counts", action="store_true", help="one more pass that prints the state's counts frame by frame")
+a = ap.parse_args()
+n_frames, depth = a.frames, a.depth
 K = synth.KITTI_K
-frames, poses, lift = synth.plane_sequence(n_frames, K, nv=376, nu=1241, depth=20.0, step=(0.2, 0.0, 0.15))
+frames, poses, lift = synth.plane_sequence(n_frames, K, nv=376, nu=1241, depth=20.0, step=(0.2, 0.0, 0.15), sigma=a.sigma)
 ctx = _lib.Context(0)
-st = synth.stress_state(K, lift, modules._new_state)
+st = synth.stress_state(K, lift, modules._new_state, max_age=a.max_age)
 dev = [torch.from_numpy(f).to("cuda:0") for f in frames]
 loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=25000, maxCandidates=25000, CandidatesToKeep=5000, MinDistance=1.5,
-                 angularThreshold=6.0, maxTemporalRecall=16, ctx=ctx)
-for rep in range(reps):
+                 angularThreshold=a.angle, maxTemporalRecall=a.recall, ctx=ctx)
+for rep in range(a.passes):
     loop.set_state(st, dev[0]); ctx.sync()
     t0 = time.perf_counter()
     pending = 0
@@ -33,3 +41,11 @@ for rep in range(reps):
         pose, status, info = loop.collect(); pending -= 1
     dt = time.perf_counter() - t0
     print(f"pass {rep}: {1e3 * dt / (n_frames - 1):.3f} ms/frame  {info}")
+if a.counts:
+    loop.set_state(st, dev[0])
+    tot = 0
+    for k in range(1, n_frames):
+        pose, status, info = loop.processFrame(dev[k], dev[k + 1] if k + 1 < n_frames else None)
+        tot += info["n_tracked"] + info["n_candidates"]
+        print(k, {x: info[x] for x in ("n_landmarks", "n_candidates", "n_tracked", "n_promoted", "n_new")})
+    print("landmarks tracked + candidates held, mean per frame:", tot / (n_frames - 1))

@@ -711,6 +711,7 @@ struct vo_frame_state {
     // two branches of a frame (vo_frame_submit): the landmark branch on the ctx's lane stream, the rest on the ctx stream
     hipEvent_t ev_state = nullptr;          // ctx stream: the next state's landmarks are in place (k_compact2)
     hipEvent_t ev_pose = nullptr;           // lane: pose, reprojection filter and its compaction are done
+    hipEvent_t ev_ltrack = nullptr;         // lane: the landmarks' tracking launch is done (large states: the candidates' starts behind it)
     bool state_event = false;               // ev_state stands for the current state (false after set_state / set_image)
     bool overlap = true;                    // VO_FRAME_SERIAL=1: both branches on the ctx stream
     hipEvent_t ev_rec[VO_FRAME_MAX_PENDING] = {};
@@ -812,6 +813,7 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_fork_la, vo_int_event_flags());
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_state, vo_int_event_flags());
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_pose, vo_int_event_flags());
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_ltrack, vo_int_event_flags());
     st->overlap = !getenv("VO_FRAME_SERIAL");
     if (const char* sp = getenv("VO_FRAME_STAMPS")) {
         st->stamp_path = sp;
@@ -851,6 +853,7 @@ int vo_frame_destroy(vo_ctx* ctx, vo_frame_state* st) {
     if (st->ev_fork_la) (void)hipEventDestroy(st->ev_fork_la);
     if (st->ev_state) (void)hipEventDestroy(st->ev_state);
     if (st->ev_pose) (void)hipEventDestroy(st->ev_pose);
+    if (st->ev_ltrack) (void)hipEventDestroy(st->ev_ltrack);
     for (int k = 0; k < 2; ++k) if (st->ev_detect[k]) (void)hipEventDestroy(st->ev_detect[k]);
     for (int k = 0; k < VO_FRAME_MAX_PENDING; ++k) if (st->ev_rec[k]) (void)hipEventDestroy(st->ev_rec[k]);
     if (st->h_counts) (void)hipHostFree(st->h_counts);
@@ -1079,6 +1082,11 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     // compaction are sized by the capacity and read M themselves.
     if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->kp[s], st->kp[s] + cl, cl, o.klt.block_w, o.klt.block_h,
                             o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, /* scores: processFrame discards them, :278 */ nullptr, nullptr, st->sizes + 0))) { leave_lane(); return rc; }
+    // Large states: two tracking launches that start together share the chip and end together, and the pose chain -- the
+    // frame's critical path -- starts when both are done.  The candidates' launch starts behind the landmarks' instead (it
+    // is needed from the triangulation on) and runs beside the pose chain, whose one-wave kernels take the holes it leaves.
+    const bool l_first = wide && sl != sm && !getenv("VO_FRAME_TRACKS_TOGETHER");
+    if (l_first) ST_CHECK(hipEventRecord(st->ev_ltrack, sl));
     stamp(sl, 1);
     {   // (the frame's counters and tombstones are cleared by the same launch)
         TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
@@ -1121,6 +1129,7 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     if (st->next_src) ST_CHECK(hipEventRecord(st->ev_fork_la, sm));
     stamp(sm, 5);
     // :71 track the candidates: points from the state, results straight into the candidates' work arrays
+    if (l_first) ST_CHECK(hipStreamWaitEvent(sm, st->ev_ltrack, 0));
     if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->cu[s], st->cu[s] + cc, cc, o.klt.block_w, o.klt.block_h,
                             o.klt.max_iters, eps, o.klt.max_bidir_err, st->cq, st->cq + cc, st->cvalid, /* :71 `~` */ nullptr, nullptr, st->sizes + 1))) return rc;
     stamp(sm, 6);

@@ -142,13 +142,14 @@ def triangulation_scene(n, seed=8191, K=KITTI_K, nv=376, nu=1241, noise=0.2, n_p
     return xy0, xy1, poses0, pose1, X
 
 
-def plane_sequence(n_frames, K, nv=240, nu=320, seed=77, depth=12.0, step=(0.12, 0.02, 0.10), yaw_deg=0.15, noise=0.5):
+def plane_sequence(n_frames, K, nv=240, nu=320, seed=77, depth=12.0, step=(0.12, 0.02, 0.10), yaw_deg=0.15, noise=0.5, sigma=2.0):
     """A 3D-consistent sequence for the frame loop (modules/VisualOdometry.m:264-346): a textured
     fronto-parallel plane Z = depth (world = camera 0) seen by a camera that moves by `step` metres
     and turns by `yaw_deg` per frame.  Returns frames (uint8), poses (4x3 [R_cw; C] each) and a
-    function lifting frame-0 pixels to their landmarks on the plane."""
+    function lifting frame-0 pixels to their landmarks on the plane.  sigma: the texture's blur (2 px: ~13k min-eigen
+    corners on a KITTI-sized frame; 1 px: four times as many)."""
     margin = 96
-    tex = texture(nv, nu, seed, margin=margin)
+    tex = texture(nv, nu, seed, sigma=sigma, margin=margin)
     vv, uu = np.mgrid[0:nv, 0:nu].astype(np.float64)
     Kinv = np.linalg.inv(K)
     rays = np.stack([uu.ravel(), vv.ravel(), np.ones(uu.size)], 0)
