@@ -216,6 +216,59 @@ def test_merge_at_the_stress_size(ctx):
     loop.close()
 
 
+@pytest.mark.parametrize("depth", [1, 2])
+def test_large_states_take_one_wave_compactions_with_the_same_bits(ctx, depth, monkeypatch):
+    """States beyond 2048 entries run their ordered compactions as launches of one-wave workgroups that publish their
+    counts (compact_wave; k_tracked_w, k_pose_tail_w, k_merge_list_w, k_merge_write_w, k_compact2_w) and start the
+    candidates' tracking launch behind the landmarks'.  A chain of frames on a KITTI-shaped sequence -- 3000 landmarks at
+    the cap, 3000 seeded candidates of which a few hundred are promoted a frame, new candidates every frame, the
+    look-ahead on -- gives the bits of the one-block kernels (VO_FRAME_NARROW=1, read at every submit), frame by frame
+    and in the final state; and the first frame matches the oracle's restatement of processFrame."""
+    KK = synth.KITTI_K
+    frames, poses, lift = synth.plane_sequence(8, KK, nv=376, nu=1241, depth=20.0, step=(0.2, 0.0, 0.15))
+    st0 = synth.stress_state(KK, lift, vo_frame.new_state, 3000, 3000, max_age=20)
+    kw = dict(maxNumLandmarks=3000, maxCandidates=6000, CandidatesToKeep=400, MinDistance=3.0, angularThreshold=12.0,
+              maxTemporalRecall=24)
+
+    def run(narrow):
+        if narrow:
+            monkeypatch.setenv("VO_FRAME_NARROW", "1")
+        else:
+            monkeypatch.delenv("VO_FRAME_NARROW", raising=False)
+        loop = FrameLoop(KK, frames[0].shape, ctx=ctx, **kw)
+        loop.set_state(st0, frames[0])
+        got, pending = [], 0
+        for k in range(1, len(frames)):
+            nxt = frames[k + 1] if k + 1 < len(frames) else None
+            if depth == 1:
+                got.append(loop.processFrame(frames[k], nxt))
+            else:
+                loop.submit(frames[k], nxt); pending += 1
+                if pending == depth:
+                    got.append(loop.collect()); pending -= 1
+        while pending:
+            got.append(loop.collect()); pending -= 1
+        final = loop.get_state()
+        loop.close()
+        return got, final
+    wide, wide_final = run(False)
+    narrow, narrow_final = run(True)
+    monkeypatch.delenv("VO_FRAME_NARROW", raising=False)
+    assert sum(i["n_promoted"] for _, _, i in wide) > 500 and sum(i["n_new"] for _, _, i in wide) > 500
+    for (p0, s0, i0), (p1, s1, i1) in zip(wide, narrow):
+        assert np.array_equal(p0, p1) and s0 == s1 and i0 == i1
+    assert states_equal(wide_final, narrow_final)
+    if depth == 1:    # one frame against the oracle, from the same state
+        loop = FrameLoop(KK, frames[0].shape, ctx=ctx, **kw)
+        loop.set_state(st0, frames[0])
+        gpose, gstatus, ginfo = loop.processFrame(frames[1])
+        o, pose, status, info = vo_frame.process_frame(frames[0], frames[1], st0, KK, 1, maxNumLandmarks=3000, keep=400,
+                                                       min_distance=3.0, angularThreshold=12.0, maxTemporalRecall=24, threads=16)
+        assert gstatus == status == 0 and ginfo["n_promoted"] == info["promoted"]
+        assert_states_match(loop.get_state(), o)
+        loop.close()
+
+
 def synth_lift_at(pose, u, v, depth=12.0):
     """landmarks on the plane Z = depth seen at pixel (u, v) from `pose` ([R_cw; C])"""
     R, C = pose[:3], pose[3]

@@ -776,8 +776,9 @@ __global__ __launch_bounds__(64) void k_p3p_batch(const double* P, const double*
 static int score_chunks(int nblocks, int npoints) {
     // one-wave blocks: split the points over blockIdx.y until the launch has about 4 waves per SIMD (a piece no
     // shorter than 1024 points = 4 passes of a wave)
+    static const int target = [] { const char* e = getenv("VO_SCORE_BLOCKS"); return e ? atoi(e) : 3072; }();   // A/B switch
     int c = 1;
-    while (c < 64 && nblocks * c < 3072 && npoints / (2 * c) >= 1024) c *= 2;
+    while (c < 64 && nblocks * c < target && npoints / (2 * c) >= 1024) c *= 2;
     return c;
 }
 
