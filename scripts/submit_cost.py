@@ -1,3 +1,5 @@
+"""Host time of vo_frame_submit and the loop's rate with four frames in flight.
+    python scripts/submit_cost.py [host]      host: hand over host images (numpy) instead of device images"""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch
@@ -9,7 +11,8 @@ frames, poses, lift = synth.plane_sequence(n_frames, K, nv=376, nu=1241, depth=2
 ctx = _lib.Context(0)
 kp = ops.select_candidates(frames[0], np.zeros((0, 2), np.float32), min_distance=7, min_quality=0.001, keep=300, index_base=0, ctx=ctx).astype(np.float64)
 st = modules._new_state(); st.keypoints = kp; st.landmarks = lift(kp[:, 0], kp[:, 1]); st.reproError = np.zeros(len(kp)); st.candidate_first_poses = np.zeros((0, 4, 3))
-dev = [torch.from_numpy(f).to("cuda:0") for f in frames]
+host = len(sys.argv) > 1 and sys.argv[1] == "host"
+dev = [np.ascontiguousarray(f) for f in frames] if host else [torch.from_numpy(f).to("cuda:0") for f in frames]
 loop = FrameLoop(K, frames[0].shape, ctx=ctx)
 for rep in range(4):
     loop.set_state(st, dev[0]); ctx.sync()

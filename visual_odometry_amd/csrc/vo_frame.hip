@@ -707,6 +707,14 @@ struct vo_frame_state {
     unsigned chain_epoch = 0;               // one per wide compaction launched
     int32_t* h_counts;                      // pinned
     double* h_rec;                          // pinned: VO_FRAME_MAX_PENDING records of 40 doubles (ransac record 16, pose 12, counters)
+    // host images go through a ring of pinned slots (one per pending frame + the look-ahead + one): the caller's buffer
+    // is read during the call by a host memcpy, the upload from the slot is a truly asynchronous copy -- a pageable
+    // source would make the runtime wait until the stream has reached the copy, behind the previous frame's chain
+    static constexpr int PIN_SLOTS = VO_FRAME_MAX_PENDING + 2;
+    uint8_t* h_img[PIN_SLOTS] = {};
+    hipEvent_t ev_img[PIN_SLOTS] = {};      // the upload out of slot r is done (the slot may be written again)
+    bool img_used[PIN_SLOTS] = {};
+    int pin_next = 0;
     // frames submitted and not collected yet, oldest first
     // two branches of a frame (vo_frame_submit): the landmark branch on the ctx's lane stream, the rest on the ctx stream
     hipEvent_t ev_state = nullptr;          // ctx stream: the next state's landmarks are in place (k_compact2)
@@ -761,8 +769,22 @@ void carve(vo_frame_state* st, char* base, size_t* total) {
 }
 int copy_image(vo_ctx* ctx, vo_frame_state* st, int slot, const uint8_t* img, int on_device, hipStream_t stream = nullptr) {
     const size_t nb = (size_t)st->nu * st->nv;
-    ST_CHECK(hipMemcpyAsync(st->img[slot], img, nb, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                            stream ? stream : ctx->stream));
+    hipStream_t q = stream ? stream : ctx->stream;
+    if (on_device) {
+        ST_CHECK(hipMemcpyAsync(st->img[slot], img, nb, hipMemcpyDeviceToDevice, q));
+        return VO_OK;
+    }
+    const int r = st->pin_next;
+    st->pin_next = (r + 1) % vo_frame_state::PIN_SLOTS;
+    if (!st->h_img[r]) {
+        ST_CHECK(hipHostMalloc((void**)&st->h_img[r], nb, 0));
+        ST_CHECK(hipEventCreateWithFlags(&st->ev_img[r], hipEventDisableTiming));
+    }
+    if (st->img_used[r]) ST_CHECK(hipEventSynchronize(st->ev_img[r]));   // PIN_SLOTS uploads ago: long done
+    memcpy(st->h_img[r], img, nb);                                         // the caller's buffer is free when the call returns
+    ST_CHECK(hipMemcpyAsync(st->img[slot], st->h_img[r], nb, hipMemcpyHostToDevice, q));
+    ST_CHECK(hipEventRecord(st->ev_img[r], q));
+    st->img_used[r] = true;
     return VO_OK;
 }
 int build_pyramid(vo_ctx* ctx, vo_frame_state* st, int slot, hipStream_t stream = nullptr) {
@@ -858,6 +880,10 @@ int vo_frame_destroy(vo_ctx* ctx, vo_frame_state* st) {
     for (int k = 0; k < VO_FRAME_MAX_PENDING; ++k) if (st->ev_rec[k]) (void)hipEventDestroy(st->ev_rec[k]);
     if (st->h_counts) (void)hipHostFree(st->h_counts);
     if (st->h_rec) (void)hipHostFree(st->h_rec);
+    for (int r = 0; r < vo_frame_state::PIN_SLOTS; ++r) {
+        if (st->ev_img[r]) (void)hipEventDestroy(st->ev_img[r]);
+        if (st->h_img[r]) (void)hipHostFree(st->h_img[r]);
+    }
     if (st->h_stamps) {
         if (FILE* fp = fopen(st->stamp_path.c_str(), "w")) {
             for (int f = 0; f < STAMP_FRAMES; ++f) {
