@@ -401,8 +401,11 @@ __device__ __forceinline__ int sieve_mark(const int32_t* qdev, int q) {
 __device__ __forceinline__ void score_body(ScoreArgs a, const double* own_poses) {
     __shared__ double sRt[SC_NS * 12];
     __shared__ int s_pid[SC_NS];
+    __shared__ int s_cnt[SC_NS];
+    __shared__ unsigned long long s_cost[SC_NS];
     if (a.M_dev) { a.M = min(a.M, *a.M_dev); if (a.M < 4) return; }
     const int tid = threadIdx.x;
+    if (tid < SC_NS) { s_cnt[tid] = 0; s_cost[tid] = 0ull; }   // (ordered before their use by the barriers below)
     const int nlist = a.list ? *a.list_n : 0;
     if (a.list && (int)blockIdx.x * SC_NS >= nlist) return;   // uniform
     if (tid < SC_NS) {
@@ -467,18 +470,33 @@ __device__ __forceinline__ void score_body(ScoreArgs a, const double* own_poses)
         }
     }
     if (c1 <= c0) return;
+    // The wave's sums per pose (integer sums: any order gives the same bits).  Most poses of most blocks have no inlier at
+    // all -- one compare and a branch; a pose with a few (a wrong pose that happens to pass near some points) adds them
+    // with LDS atomics; only a pose with inliers on many lanes -- a good one, one in eight -- pays the butterfly (18
+    // ds_bpermute and as many adds), which every pose paid before: half of the kernel's vector instructions in the short
+    // pieces the sieve's later stages are made of (SQ_INSTS_VALU per wave: 1024, of which the tests ~520).  (LDS atomics
+    // for every pose were measured too: 64 lanes on one address serialise -- 0.27 instead of 0.19 ms for the scoring.)
 #pragma unroll
     for (int s = 0; s < SC_NS; ++s) {
-        int c = cnt[s]; unsigned long long q = cost[s];
+        const unsigned long long bal = __ballot(cnt[s] != 0);
+        if (bal == 0ull) continue;
+        if (__popcll(bal) <= 4) {
+            if (cnt[s]) { atomicAdd(&s_cnt[s], cnt[s]); atomicAdd(&s_cost[s], cost[s]); }
+        } else {
+            int c = cnt[s]; unsigned long long q = cost[s];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { c += __shfl_xor(c, d, 64); q += __shfl_xor(q, d, 64); }
-        if (tid == s && s_pid[s] >= 0) {
-            const unsigned long long total = q + (unsigned long long)((c1 - c0) - c) * qthr;
-            if (own_poses) { a.cnt[s_pid[s]] = c; a.cost[s_pid[s]] = total; }
-            else {
-                if (c) atomicAdd(&a.cnt[s_pid[s]], c);
-                atomicAdd(&a.cost[s_pid[s]], total);
-            }
+            for (int d = 32; d >= 1; d >>= 1) { c += __shfl_xor(c, d, 64); q += __shfl_xor(q, d, 64); }
+            if (tid == 0) { s_cnt[s] = c; s_cost[s] = q; }
+        }
+    }
+    __syncthreads();
+    if (tid < SC_NS && s_pid[tid] >= 0) {
+        const int c = s_cnt[tid];
+        const unsigned long long total = s_cost[tid] + (unsigned long long)((c1 - c0) - c) * qthr;
+        if (own_poses) { a.cnt[s_pid[tid]] = c; a.cost[s_pid[tid]] = total; }
+        else {
+            if (c) atomicAdd(&a.cnt[s_pid[tid]], c);
+            atomicAdd(&a.cost[s_pid[tid]], total);
         }
     }
     if (tid == 0 && a.counters && !a.list && blockIdx.y == 0)
