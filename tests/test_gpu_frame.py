@@ -222,7 +222,7 @@ def test_large_states_take_one_wave_compactions_with_the_same_bits(ctx, depth, m
     counts (compact_wave; k_tracked_w, k_pose_tail_w, k_merge_list_w, k_merge_write_w, k_compact2_w) and start the
     candidates' tracking launch behind the landmarks'.  A chain of frames on a KITTI-shaped sequence -- 3000 landmarks at
     the cap, 3000 seeded candidates of which a few hundred are promoted a frame, new candidates every frame, the
-    look-ahead on -- gives the bits of the one-block kernels (VO_FRAME_NARROW=1, read at every submit), frame by frame
+    look-ahead on -- gives the bits of the one-block kernels (VO_FRAME_NARROW=1, read when a loop is created), frame by frame
     and in the final state; and the first frame matches the oracle's restatement of processFrame."""
     KK = synth.KITTI_K
     frames, poses, lift = synth.plane_sequence(8, KK, nv=376, nu=1241, depth=20.0, step=(0.2, 0.0, 0.15))

@@ -722,6 +722,8 @@ struct vo_frame_state {
     hipEvent_t ev_ltrack = nullptr;         // lane: the landmarks' tracking launch is done (large states: the candidates' starts behind it)
     bool state_event = false;               // ev_state stands for the current state (false after set_state / set_image)
     bool overlap = true;                    // VO_FRAME_SERIAL=1: both branches on the ctx stream
+    bool narrow = false;                    // VO_FRAME_NARROW=1: one-block compactions at every size (A/B switch, read at create)
+    bool tracks_together = false;           // VO_FRAME_TRACKS_TOGETHER=1: both tracking launches start together at every size
     hipEvent_t ev_rec[VO_FRAME_MAX_PENDING] = {};
     long long* h_stamps = nullptr;          // VO_FRAME_STAMPS=<file>: device clock at 16 points of each frame (diagnosis only)
     std::string stamp_path;
@@ -837,6 +839,8 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_pose, vo_int_event_flags());
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_ltrack, vo_int_event_flags());
     st->overlap = !getenv("VO_FRAME_SERIAL");
+    st->narrow = getenv("VO_FRAME_NARROW") != nullptr;
+    st->tracks_together = getenv("VO_FRAME_TRACKS_TOGETHER") != nullptr;
     if (const char* sp = getenv("VO_FRAME_STAMPS")) {
         st->stamp_path = sp;
         if (const char* mk = getenv("VO_FRAME_STAMP_MASK")) st->stamp_mask = (unsigned)strtoul(mk, nullptr, 0);
@@ -1094,7 +1098,7 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     }
     auto leave_lane = [&]() { ctx->stream = sm; ctx->in_lane = false; };
     // large states: the ordered compactions as launches of one-wave workgroups (compact_wave) instead of one block each
-    const bool wide = (cl > 2048 || cc > 2048) && cw_blocks(pw) <= CW_MAX_BLOCKS && !getenv("VO_FRAME_NARROW");
+    const bool wide = (cl > 2048 || cc > 2048) && cw_blocks(pw) <= CW_MAX_BLOCKS && !st->narrow;
     auto chain = [&](int site) {
         if (++st->chain_epoch == 0) ++st->chain_epoch;     // 0 is what a never-written word holds
         return Chain{st->chain + (size_t)site * CW_MAX_BLOCKS, st->chain_epoch};
@@ -1111,7 +1115,7 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     // Large states: two tracking launches that start together share the chip and end together, and the pose chain -- the
     // frame's critical path -- starts when both are done.  The candidates' launch starts behind the landmarks' instead (it
     // is needed from the triangulation on) and runs beside the pose chain, whose one-wave kernels take the holes it leaves.
-    const bool l_first = wide && sl != sm && !getenv("VO_FRAME_TRACKS_TOGETHER");
+    const bool l_first = wide && sl != sm && !st->tracks_together;
     if (l_first) ST_CHECK(hipEventRecord(st->ev_ltrack, sl));
     stamp(sl, 1);
     {   // (the frame's counters and tombstones are cleared by the same launch)
