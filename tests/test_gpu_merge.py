@@ -1,8 +1,8 @@
 """The sort-based merge (vo_dev_merge_ranks; what the device-resident frame loop runs for large pools, csrc/vo_frame.hip)
 against the SEQUENTIAL policy of modules/VisualOdometry.m:87-142 walked candidate by candidate on the host (a heap holds
 the landmark set: the first maximum is the largest error, earliest in the list among equals) -- accepted and surviving
-sets entry by entry, on tie-heavy random pools from a handful of entries to 60 000 (several sort tiles, partner runs
-shorter than their neighbours, the cap reached early, late and never)."""
+sets entry by entry, on tie-heavy random pools from a handful of entries to 140 000 (several sort tiles; beyond 32 tiles
+the runs are doubled first, with partner runs shorter than their neighbours; the cap reached early, late and never)."""
 import ctypes as C
 import heapq
 
@@ -43,7 +43,8 @@ def device(ctx, torch, init, cand, cap):
 @pytest.mark.parametrize("n0,n_c,cap,levels", [
     (0, 1, 1, 2), (3, 0, 5, 2), (5, 9, 5, 3), (12, 40, 12, 4), (100, 300, 150, 5), (2047, 1, 2047, 7), (2048, 1, 2048, 3),
     (1500, 600, 1500, 6), (2000, 2100, 2048, 9), (4000, 2500, 5000, 11), (25000, 6000, 25000, 50), (25000, 6000, 25000, 100000),
-    (20000, 30000, 25000, 17), (300, 59000, 40000, 5), (30000, 30000, 100, 12), (6000, 100, 0, 3)])
+    (20000, 30000, 25000, 17), (300, 59000, 40000, 5), (30000, 30000, 100, 12), (6000, 100, 0, 3),
+    (40000, 45000, 50000, 9), (70000, 70001, 70000, 100000)])
 def test_sorted_merge_equals_the_sequential_policy(ctx, n0, n_c, cap, levels):
     import torch
     rng = np.random.default_rng(n0 * 7 + n_c + cap)

@@ -36,18 +36,21 @@ __device__ __forceinline__ int block_excl_scan_1024(int flag, int* total, int* s
     return base + within;
 }
 
-// ordered compaction by one block: Op::flag(i) says whether element i stays, Op::move(i, d) puts it at
-// position d of the output; *count = number kept.  The block walks the n elements 1024 at a time.
+// ordered compaction by one block: Op::load(i) reads element i (what decides and what moves, in one batch of loads:
+// a flag read first and the sources read behind a branch are two memory latencies in a row), Op::flag(regs) says
+// whether it stays, Op::store(d, regs) puts it at position d of the output; *count = number kept.  The block walks the
+// n elements 1024 at a time.
 template <class Op>
 __device__ __forceinline__ void compact_block(const Op& op, int n, int32_t* count, const int32_t* n_dev, int* s_w) {
     if (n_dev) n = min(n, *n_dev);   // the count lives on the device, n is its upper bound
     int base = 0;
     for (int i0 = 0; i0 < n; i0 += 1024) {
         const int i = i0 + (int)threadIdx.x;
-        const int f = (i < n && op.flag(i)) ? 1 : 0;
+        const typename Op::Regs r = op.load(i < n ? i : 0);
+        const int f = ((i < n) & op.flag(r)) ? 1 : 0;
         int tot;
         const int pos = block_excl_scan_1024(f, &tot, s_w);
-        if (f) op.move(i, base + pos);
+        if (f) op.store(base + pos, r);
         base += tot;
     }
     if (threadIdx.x == 0 && count) *count = base;
@@ -118,12 +121,18 @@ __device__ __forceinline__ int wave_positions(const Chain& ch, Keep keep, int (&
 template <class Op>
 __device__ __forceinline__ void compact_wave(const Op& op, int n, const Chain& ch, int32_t* count, int32_t* count_clamped = nullptr, int cap = 0) {
     const int i0 = blockIdx.x * CW_BLOCK + (int)threadIdx.x;
+    // every row's loads first, in one batch (rows beyond n read element 0 and are dropped): a wave that reads a row's
+    // flag, branches, reads the row's sources, stores and goes on to the next row waits for memory sixteen times in a
+    // row -- 15-25 us for a launch whose work is nothing
+    typename Op::Regs r[CW_EPL];
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k) { const int i = i0 + 64 * k; r[k] = op.load(i < n ? i : 0); }
     int pos[CW_EPL], tot;
     unsigned fbits;
-    const int base = wave_positions(ch, [&](int k) { const int i = i0 + 64 * k; return i < n && op.flag(i); }, pos, fbits, &tot);
+    const int base = wave_positions(ch, [&](int k) { return (i0 + 64 * k < n) & op.flag(r[k]); }, pos, fbits, &tot);
 #pragma unroll
     for (int k = 0; k < CW_EPL; ++k)
-        if ((fbits >> k) & 1u) op.move(i0 + 64 * k, base + pos[k]);
+        if ((fbits >> k) & 1u) op.store(base + pos[k], r[k]);
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         if (count) *count = base + tot;
         if (count_clamped) *count_clamped = base + tot < cap ? base + tot : cap;
@@ -141,20 +150,22 @@ __global__ __launch_bounds__(64) void k_compact2_w(OpA a, int na, int32_t* count
 // landmarks whose keypoint tracked validly (:280-281): (q, L) -> (vk, vl), pitch = capL
 struct TrackedOp {
     const uint8_t* valid; const double *qu, *qv, *L; int capL; double *vk, *vl;
-    __device__ bool flag(int i) const { return valid[i] != 0; }
-    __device__ void move(int i, int d) const {
-        vk[d] = qu[i]; vk[capL + d] = qv[i];
-        vl[d] = L[i]; vl[capL + d] = L[capL + i]; vl[2 * capL + d] = L[2 * capL + i];
+    struct Regs { uint8_t ok; double u, v, x, y, z; };
+    __device__ Regs load(int i) const { return {valid[i], qu[i], qv[i], L[i], L[capL + i], L[2 * capL + i]}; }
+    __device__ bool flag(const Regs& r) const { return r.ok != 0; }
+    __device__ void store(int d, const Regs& r) const {
+        vk[d] = r.u; vk[capL + d] = r.v;
+        vl[d] = r.x; vl[capL + d] = r.y; vl[2 * capL + d] = r.z;
     }
 };
 // :302 strict <, :308-315 survivors into the merge work arrays (pitch PW), alive = 1
 struct KeptOp {
     const double* err; double thr; const double *vk, *vl; int capL, PW; double *wkp, *wL, *wrep; uint8_t* alive;
-    __device__ bool flag(int i) const { return err[i] < thr; }
-    __device__ void move(int i, int d) const {
-        wkp[d] = vk[i]; wkp[PW + d] = vk[capL + i];
-        wL[d] = vl[i]; wL[PW + d] = vl[capL + i]; wL[2 * PW + d] = vl[2 * capL + i];
-        wrep[d] = err[i];
+    // (the pose tail has the element in registers when it decides: keypoint, landmark, error)
+    __device__ void store(int d, double ku, double kv, double x, double y, double z, double e) const {
+        wkp[d] = ku; wkp[PW + d] = kv;
+        wL[d] = x; wL[PW + d] = y; wL[2 * PW + d] = z;
+        wrep[d] = e;
         alive[d] = 1;
     }
 };
@@ -193,9 +204,10 @@ __global__ __launch_bounds__(1024) void k_pose_tail(PoseTailArgs a) {
         const int i = i0 + tid;
         bool in = false;
         int f = 0;
+        double Xi[3] = {0.0, 0.0, 0.0}, x = 0.0, y = 0.0, e = 0.0;
         if (i < Md) {
-            const double Xi[3] = {a.vl[i], a.vl[a.capL + i], a.vl[2 * a.capL + i]};
-            const double x = a.vk[i], y = a.vk[a.capL + i];
+            Xi[0] = a.vl[i]; Xi[1] = a.vl[a.capL + i]; Xi[2] = a.vl[2 * a.capL + i];
+            x = a.vk[i]; y = a.vk[a.capL + i];
             if (solved) {
                 const ProjT p = proj_terms(P, Xi[0], Xi[1], Xi[2], x, y);
                 in = p.ez < a.thr2 * p.z2;
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(1024) void k_pose_tail(PoseTailArgs a) {
             double u, v, w;
             project(cam, Xi, u, v, w);
             const double du = x - u, dv = y - v;
-            const double e = sqrt(du * du + dv * dv);
+            e = sqrt(du * du + dv * dv);
             a.err[i] = e;
             f = e < a.kop.thr ? 1 : 0;
         }
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(1024) void k_pose_tail(PoseTailArgs a) {
         if ((tid & 63) == 0) n_in += __popcll(bal);
         int tot;
         const int pos = block_excl_scan_1024(f, &tot, s_w);
-        if (f) a.kop.move(i, base + pos);
+        if (f) a.kop.store(base + pos, x, y, Xi[0], Xi[1], Xi[2], e);
         base += tot;
     }
     if ((tid & 63) == 0 && n_in) atomicAdd(&info[4], n_in);
@@ -241,33 +253,38 @@ __global__ __launch_bounds__(64) void k_pose_tail_w(PoseTailArgs a, Chain ch) {
     for (int k = 0; k < 9; ++k) K[k] = a.K[k];
     camera_matrix(s_pose, K, cam);
     const int i0 = blockIdx.x * CW_BLOCK + tid;
+    // all rows' loads in one batch (rows beyond the tracked landmarks read element 0 and are dropped), then the arithmetic
+    double X0[CW_EPL], X1[CW_EPL], X2[CW_EPL], kx[CW_EPL], ky[CW_EPL], er[CW_EPL];
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k) {
+        const int i = i0 + 64 * k, ic = i < Md ? i : 0;
+        X0[k] = a.vl[ic]; X1[k] = a.vl[a.capL + ic]; X2[k] = a.vl[2 * a.capL + ic];
+        kx[k] = a.vk[ic]; ky[k] = a.vk[a.capL + ic];
+    }
     int n_in = 0;
-    int pos[CW_EPL], tot;
-    unsigned fbits;
-    const int base = wave_positions(ch, [&](int k) {
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k) {
         const int i = i0 + 64 * k;
-        bool in = false, f = false;
-        if (i < Md) {
-            const double Xi[3] = {a.vl[i], a.vl[a.capL + i], a.vl[2 * a.capL + i]};
-            const double x = a.vk[i], y = a.vk[a.capL + i];
-            if (solved) {
-                const ProjT p = proj_terms(P, Xi[0], Xi[1], Xi[2], x, y);
-                in = p.ez < a.thr2 * p.z2;
-            }
-            double u, v, w;
-            project(cam, Xi, u, v, w);
-            const double du = x - u, dv = y - v;
-            const double e = sqrt(du * du + dv * dv);
-            a.err[i] = e;
-            f = e < a.kop.thr;
+        const double Xi[3] = {X0[k], X1[k], X2[k]};
+        bool in = false;
+        if (solved) {
+            const ProjT p = proj_terms(P, Xi[0], Xi[1], Xi[2], kx[k], ky[k]);
+            in = (i < Md) & (p.ez < a.thr2 * p.z2);
         }
+        double u, v, w;
+        project(cam, Xi, u, v, w);
+        const double du = kx[k] - u, dv = ky[k] - v;
+        er[k] = sqrt(du * du + dv * dv);
+        if (i < Md) a.err[i] = er[k];
         if (i < a.capL) a.inl[i] = in ? 1 : 0;
         n_in += __popcll(__ballot(in));
-        return f;
-    }, pos, fbits, &tot);
+    }
+    int pos[CW_EPL], tot;
+    unsigned fbits;
+    const int base = wave_positions(ch, [&](int k) { return (i0 + 64 * k < Md) & (er[k] < a.kop.thr); }, pos, fbits, &tot);
 #pragma unroll
     for (int k = 0; k < CW_EPL; ++k)
-        if ((fbits >> k) & 1u) a.kop.move(i0 + 64 * k, base + pos[k]);
+        if ((fbits >> k) & 1u) a.kop.store(base + pos[k], kx[k], ky[k], X0[k], X1[k], X2[k], er[k]);
     if (tid == 0 && n_in) atomicAdd(&info[4], n_in);
     if (blockIdx.x == gridDim.x - 1 && tid == 0) *a.count = base + tot;
 }
@@ -275,33 +292,38 @@ __global__ __launch_bounds__(64) void k_pose_tail_w(PoseTailArgs a, Chain ch) {
 // :106-113, :130: 0 drop, 1 promote (angle large), 2 keep as candidate (angle small, young enough)
 struct ClassifyArgs {
     const uint8_t *tracked, *ok; const double *rep, *ang; const int32_t* ctime; double max_rep, ang_thr; int recall;
-    __device__ int cls(int i) const {
-        if (tracked[i] && ok[i] && rep[i] <= max_rep) {
-            if (ang[i] > ang_thr) return 1;
-            if (ctime[i] > -recall) return 2;
-        }
-        return 0;
+    struct Regs { uint8_t t, o; double rep, ang; int32_t ct; };
+    __device__ Regs load(int i) const { return {tracked[i], ok[i], rep[i], ang[i], ctime[i]}; }
+    // (no branch between the loads: five reads, one wait)
+    __device__ int cls_of(const Regs& r) const {
+        const bool good = (r.t != 0) & (r.o != 0) & (r.rep <= max_rep);
+        return good ? (r.ang > ang_thr ? 1 : (r.ct > -recall ? 2 : 0)) : 0;
     }
+    __device__ int cls(int i) const { return cls_of(load(i)); }
 };
 // :130-139 kept candidates, aged by one frame
 struct CandOp {
     ClassifyArgs c; int capC; const double *cq, *cf; const int32_t *cpose, *ctime; double *ncu, *ncf; int32_t *ncpose, *nctime;
-    __device__ bool flag(int i) const { return c.cls(i) == 2; }
-    __device__ void move(int i, int d) const {
-        ncu[d] = cq[i]; ncu[capC + d] = cq[capC + i];
-        ncf[d] = cf[i]; ncf[capC + d] = cf[capC + i];
-        ncpose[d] = cpose[i]; nctime[d] = ctime[i] - 1;
+    struct Regs { ClassifyArgs::Regs c; double qu, qv, fu, fv; int32_t pose; };
+    __device__ Regs load(int i) const { return {c.load(i), cq[i], cq[capC + i], cf[i], cf[capC + i], cpose[i]}; }   // (c.ctime is ctime)
+    __device__ bool flag(const Regs& r) const { return c.cls_of(r.c) == 2; }
+    __device__ void store(int d, const Regs& r) const {
+        ncu[d] = r.qu; ncu[capC + d] = r.qv;
+        ncf[d] = r.fu; ncf[capC + d] = r.fv;
+        ncpose[d] = r.pose; nctime[d] = r.c.ct - 1;
     }
 };
 // the live landmarks, in order, into the next state (pitch capL)
 struct LandmarkOp {
     const uint8_t* alive; int PW, capL; const double *wkp, *wL, *wrep; double *kp, *L, *rep;
-    __device__ bool flag(int i) const { return alive[i] != 0; }
-    __device__ void move(int i, int d) const {
+    struct Regs { uint8_t alive; double ku, kv, x, y, z, e; };
+    __device__ Regs load(int i) const { return {alive[i], wkp[i], wkp[PW + i], wL[i], wL[PW + i], wL[2 * PW + i], wrep[i]}; }
+    __device__ bool flag(const Regs& r) const { return r.alive != 0; }
+    __device__ void store(int d, const Regs& r) const {
         if (d >= capL) return;
-        kp[d] = wkp[i]; kp[capL + d] = wkp[PW + i];
-        L[d] = wL[i]; L[capL + d] = wL[PW + i]; L[2 * capL + d] = wL[2 * PW + i];
-        rep[d] = wrep[i];
+        kp[d] = r.ku; kp[capL + d] = r.kv;
+        L[d] = r.x; L[capL + d] = r.y; L[2 * capL + d] = r.z;
+        rep[d] = r.e;
     }
 };
 // start of a frame: the frame's counters and the tombstone array are cleared.  The two track calls of a frame (:278
@@ -448,12 +470,23 @@ __global__ __launch_bounds__(1024) void k_merge_par(MergeArgs a, CandOp cop, int
 //               strictly smaller keys of that left run (a binary search the merge needs anyway) is that level's share;
 //   rank(e)   = #{x : v_x < v_e} + #{x : v_x = v_e, x later}: e's place in the sorted sequence with the ties of equal
 //               keys reversed -- its sorted position mirrored inside its group of equal keys.
-// Launches: the list and the pool (one block), runs of SORT_TILE elements sorted in LDS (one block per run), one launch
-// per remaining doubling of the run length, the ranks, the ordered write (one block).  Keys beyond the pool are +inf
-// (never below or equal to a real key: reproError is finite wherever the classes let a candidate in).
+// Launches: the list and the pool, runs of SORT_TILE elements sorted in LDS (one block per run), then -- the runs are
+// never merged into one sequence, the two counts are all the policy needs -- ONE launch in which every element looks
+// itself up in every run (k_sort_decide: up to SORT_WAYS binary searches side by side instead of log2(runs) dependent
+// launches of one search each; 40 us of merge levels + 9 us of ranks -> one launch at the stress size).  Pools of more
+// than SORT_WAYS runs first double their run length (k_sort_merge) until SORT_WAYS runs are left: O(n log n) either way.
+// Then the ordered write.  Keys beyond the pool are +inf (never below or equal to a real key: reproError is finite
+// wherever the classes let a candidate in).
 // pool: the keys in pool order; key / idx: two buffers each of the padded length; before: one int per pool entry.
 struct MergeWideArgs { MergeArgs m; double* pool; uint8_t *surv, *acc; int32_t* np_out; double* key[2]; int32_t* idx[2]; int32_t* before; int padded; };
 constexpr int SORT_TILE = 2048;     // elements sorted by one block in LDS (2 per thread: every step of a level is a chain of dependent LDS reads)
+constexpr int SORT_WAYS = 32;       // runs that k_sort_decide looks through per element (a choice of speed: any number is right)
+// the run length the decisions are taken at, for a pool of (about) P entries
+static inline int sort_decide_run(long P) {
+    int L = SORT_TILE;
+    while ((P + L - 1) / L > SORT_WAYS) L <<= 1;
+    return L;
+}
 
 __global__ __launch_bounds__(1024) void k_merge_list(MergeWideArgs w) {
     __shared__ int s_w[16];
@@ -503,6 +536,12 @@ __global__ __launch_bounds__(1024) void k_sort_tiles(MergeWideArgs w) {
     __shared__ int32_t s_before[SORT_TILE];
     const int P = *w.m.n0 + *w.np_out;
     const int t0 = blockIdx.x * SORT_TILE;
+    if (t0 >= P) {      // a tile of padding (the buffers are sized for the full state): in order as it is
+        for (int k = threadIdx.x; k < SORT_TILE; k += 1024) {
+            w.key[0][t0 + k] = __builtin_huge_val(); w.idx[0][t0 + k] = t0 + k; w.before[t0 + k] = 0;
+        }
+        return;
+    }
     for (int k = threadIdx.x; k < SORT_TILE; k += 1024) {
         const int e = t0 + k;
         s_key[0][k] = e < P ? w.pool[e] : __builtin_huge_val();
@@ -510,15 +549,40 @@ __global__ __launch_bounds__(1024) void k_sort_tiles(MergeWideArgs w) {
         s_before[k] = 0;
     }
     __syncthreads();
+    // A level: every element counts the keys of its partner run that are < its own -- a search of log2(L) + 1 steps
+    // whatever the element, so a wave does not diverge and the two elements of a thread are searched side by side (a
+    // level is a chain of dependent LDS reads: this is what it costs).  For a left-hand element that count is its
+    // shift; a right-hand element is shifted by the keys <= its own, which differ from the count only where the
+    // partner holds an equal key (a second search, taken by the lanes that meet one).
     int cur = 0;
     for (int L = 1; L < SORT_TILE; L <<= 1) {
-        for (int k = threadIdx.x; k < SORT_TILE; k += 1024) {
-            const double v = s_key[cur][k];
+        const double* key = s_key[cur];
+        double v[2]; int pb[2], lb[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = threadIdx.x + 1024 * q;
+            v[q] = key[k];
+            pb[q] = (k & ~(2 * L - 1)) + ((k & L) ? 0 : L);       // the partner run's first element
+            lb[q] = 0;
+        }
+        for (int s2 = L >> 1; s2 >= 1; s2 >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) lb[q] += key[pb[q] + lb[q] + s2 - 1] < v[q] ? s2 : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) lb[q] += key[pb[q] + lb[q]] < v[q] ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int k = threadIdx.x + 1024 * q;
             const int i = s_idx[cur][k];
-            int sm;
-            const int d = merge_place(s_key[cur], k, L, v, &sm);
-            s_key[cur ^ 1][d] = v; s_idx[cur ^ 1][d] = i;
-            if (sm) s_before[i - t0] += sm;      // every element has one thread per level: no two writers
+            const int base = k & ~(2 * L - 1);
+            int shift = lb[q];
+            if (k & L) {                                           // right-hand run: behind the left keys that are <= v
+                if (lb[q] < L && key[pb[q] + lb[q]] <= v[q]) shift = bound<true>(key, pb[q] + lb[q], pb[q] + L, v[q]) - pb[q];
+                if (lb[q]) s_before[i - t0] += lb[q];              // every element has one thread per level: no two writers
+            }
+            const int d = base + (k & (L - 1)) + shift;
+            s_key[cur ^ 1][d] = v[q]; s_idx[cur ^ 1][d] = i;
         }
         __syncthreads();
         cur ^= 1;
@@ -556,18 +620,73 @@ __global__ __launch_bounds__(256) void k_sort_merge(MergeWideArgs w, int L, int 
     if (sm) w.before[i] += sm;
 }
 
-// the two decisions of the merge from the sorted pool (buffer `in`)
-__global__ __launch_bounds__(256) void k_sort_ranks(MergeWideArgs w, int in) {
+// The two decisions of the merge from the sorted runs of length L (buffer `in`; L = SORT_TILE << levels merged so far).
+// One lane per sorted position; with lo_r / hi_r = the keys of run r that are < / <= the lane's own key v:
+//   before(e) = before inside e's run (counted while it was sorted) + sum of lo_r over the EARLIER runs (runs are
+//               consecutive stretches of the pool, so an earlier run holds earlier entries only);
+//   rank(e)   = sum of lo_r over all runs + the equal keys that come later in the pool: hi_r - lo_r of the later runs
+//               and, the sort being stable, the equal keys behind e in its own run.
+// A search is a fixed number of steps (L is a power of two), SORT_SIDE runs searched side by side: the loads of a step
+// are independent (the launch costs the latency of ONE search), and the lanes of a wave -- neighbours in their run --
+// walk nearly the same path through every other run.  One-wave workgroups (the launch may run beside a tracking launch).
+constexpr int SORT_SIDE = 16;       // runs searched side by side
+template <bool LE>
+__device__ __forceinline__ void search_runs(const double* key, long base0, int L, int padded, double v, int (&out)[SORT_SIDE]) {
+    const double inf = __builtin_huge_val();
+#pragma unroll
+    for (int q = 0; q < SORT_SIDE; ++q) out[q] = 0;
+    for (int s = L >> 1; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int q = 0; q < SORT_SIDE; ++q) {
+            const long i = base0 + (long)q * L + out[q] + s - 1;
+            const double k = i < padded ? key[i] : inf;
+            out[q] += (LE ? k <= v : k < v) ? s : 0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SORT_SIDE; ++q) {           // the steps above cover L - 1 keys: the last one
+        const long i = base0 + (long)q * L + out[q];
+        const double k = i < padded ? key[i] : inf;
+        out[q] += (LE ? k <= v : k < v) ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(64) void k_sort_decide(MergeWideArgs w, int L, int in) {
     const int P = *w.m.n0 + *w.np_out;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= w.padded) return;
+    const int e = w.idx[in][p];
+    if (e >= P) return;                      // padding
     const double* key = w.key[in];
     const double v = key[p];
-    const int lo = bound<false>(key, 0, P, v), hi = bound<true>(key, lo, P, v);
-    const int rank = lo + (hi - 1 - p);            // ties reversed: among equal keys the later pool entry ranks first
-    const int i = w.idx[in][p];
-    w.surv[i] = rank < w.m.cap;
-    w.acc[i] = w.before[i] < w.m.cap;
+    const int own = p / L, nruns = (P + L - 1) / L;    // (a wave lies inside one run: L is a multiple of 64)
+    const int pl = p - own * L;
+    int smaller = 0, smaller_earlier = 0, equal_later = 0;
+    for (int r0 = 0; r0 < nruns; r0 += SORT_SIDE) {
+        int lo[SORT_SIDE], hi[SORT_SIDE];
+        search_runs<false>(key, (long)r0 * L, L, w.padded, v, lo);
+        // the <= search only where another run holds an equal key (rare with measured errors); the lane's own run
+        // holds one -- the lane's -- and its equal keys are its neighbours
+        bool any_equal = false;
+#pragma unroll
+        for (int q = 0; q < SORT_SIDE; ++q) {
+            const long i = (long)(r0 + q) * L + lo[q];
+            hi[q] = lo[q];
+            any_equal |= r0 + q != own && lo[q] < L && i < w.padded && key[i] <= v;
+        }
+        if (r0 <= own && own < r0 + SORT_SIDE) any_equal |= pl + 1 < L && p + 1 < w.padded && key[p + 1] <= v;
+        if (any_equal) search_runs<true>(key, (long)r0 * L, L, w.padded, v, hi);
+#pragma unroll
+        for (int q = 0; q < SORT_SIDE; ++q) {
+            const int r = r0 + q;
+            if (r >= nruns) continue;
+            smaller += lo[q];
+            if (r < own) smaller_earlier += lo[q];
+            else if (r > own) equal_later += hi[q] - lo[q];
+            else equal_later += any_equal ? hi[q] - 1 - pl : 0;     // (no equal key behind the lane's: hi = pl + 1)
+        }
+    }
+    w.surv[e] = smaller + equal_later < w.m.cap;
+    w.acc[e] = w.before[e] + smaller_earlier < w.m.cap;
 }
 
 __global__ __launch_bounds__(1024) void k_merge_write(MergeWideArgs w) {
@@ -599,33 +718,59 @@ __global__ __launch_bounds__(64) void k_merge_list_w(MergeWideArgs w, Chain ch) 
     const MergeArgs& a = w.m;
     const int tid = threadIdx.x;
     const int n0 = *a.n0, nC = *a.nC_dev;
-    for (int e = (int)blockIdx.x * 64 + tid; e < n0; e += 64 * (int)gridDim.x) w.pool[e] = a.wrep[e];
-    const int i0 = blockIdx.x * CW_BLOCK + tid;
+    const int i0 = blockIdx.x * CW_BLOCK + tid;      // the launch covers max(landmarks, candidates): rows of both
+    ClassifyArgs::Regs c[CW_EPL];
+    double lrep[CW_EPL];
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k) {               // one batch of loads
+        const int i = i0 + 64 * k;
+        c[k] = a.c.load(i < nC ? i : 0);
+        lrep[k] = a.wrep[i < n0 ? i : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k) { const int i = i0 + 64 * k; if (i < n0) w.pool[i] = lrep[k]; }
     int pos[CW_EPL], tot;
     unsigned fbits;
-    const int base = wave_positions(ch, [&](int k) { const int i = i0 + 64 * k; return i < nC && a.c.cls(i) == 1; }, pos, fbits, &tot);
+    const int base = wave_positions(ch, [&](int k) { return (i0 + 64 * k < nC) & (a.c.cls_of(c[k]) == 1); }, pos, fbits, &tot);
 #pragma unroll
     for (int k = 0; k < CW_EPL; ++k)
-        if ((fbits >> k) & 1u) { const int i = i0 + 64 * k, d = base + pos[k]; a.plist[d] = i; w.pool[n0 + d] = a.crep[i]; }
+        if ((fbits >> k) & 1u) { const int d = base + pos[k]; a.plist[d] = i0 + 64 * k; w.pool[n0 + d] = c[k].rep; }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) *w.np_out = base + tot;
 }
 __global__ __launch_bounds__(64) void k_merge_write_w(MergeWideArgs w, Chain ch) {
     const MergeArgs& a = w.m;
     const int tid = threadIdx.x;
     const int n0 = *a.n0, np = *w.np_out;
-    for (int i = (int)blockIdx.x * 64 + tid; i < n0; i += 64 * (int)gridDim.x) a.alive[i] = w.surv[i];
     const int j0 = blockIdx.x * CW_BLOCK + tid;
+    uint8_t lsurv[CW_EPL], acc[CW_EPL], csurv[CW_EPL];
+    int32_t ci[CW_EPL];
+    double crep[CW_EPL], X0[CW_EPL], X1[CW_EPL], X2[CW_EPL], qu[CW_EPL], qv[CW_EPL];
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k) {               // first batch: the decisions and the list
+        const int j = j0 + 64 * k, jc = j < np ? j : 0;
+        lsurv[k] = w.surv[j < n0 ? j : 0];
+        acc[k] = w.acc[n0 + jc]; csurv[k] = w.surv[n0 + jc]; crep[k] = w.pool[n0 + jc];
+        ci[k] = a.plist[jc];
+    }
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k) {               // second batch: the listed candidates (a row beyond the list reads candidate 0)
+        const int i = j0 + 64 * k < np ? ci[k] : 0;
+        X0[k] = a.X[i]; X1[k] = a.X[a.capC + i]; X2[k] = a.X[2 * a.capC + i];
+        qu[k] = a.cq[i]; qv[k] = a.cq[a.capC + i];
+    }
+#pragma unroll
+    for (int k = 0; k < CW_EPL; ++k) { const int j = j0 + 64 * k; if (j < n0) a.alive[j] = lsurv[k]; }
     int pos[CW_EPL], tot;
     unsigned fbits;
-    const int base = wave_positions(ch, [&](int k) { const int j = j0 + 64 * k; return j < np && w.acc[n0 + j] != 0; }, pos, fbits, &tot);
+    const int base = wave_positions(ch, [&](int k) { return (j0 + 64 * k < np) & (acc[k] != 0); }, pos, fbits, &tot);
 #pragma unroll
     for (int k = 0; k < CW_EPL; ++k)
         if ((fbits >> k) & 1u) {
-            const int j = j0 + 64 * k, i = a.plist[j], d = n0 + base + pos[k];
-            a.wL[d] = a.X[i]; a.wL[a.PW + d] = a.X[a.capC + i]; a.wL[2 * a.PW + d] = a.X[2 * a.capC + i];
-            a.wkp[d] = a.cq[i]; a.wkp[a.PW + d] = a.cq[a.capC + i];
-            a.wrep[d] = w.pool[n0 + j];
-            a.alive[d] = w.surv[n0 + j];
+            const int d = n0 + base + pos[k];
+            a.wL[d] = X0[k]; a.wL[a.PW + d] = X1[k]; a.wL[2 * a.PW + d] = X2[k];
+            a.wkp[d] = qu[k]; a.wkp[a.PW + d] = qv[k];
+            a.wrep[d] = crep[k];
+            a.alive[d] = csurv[k];
         }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) *a.n_promoted = base + tot;
 }
@@ -1192,10 +1337,12 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
             if (wide) hipLaunchKernelGGL(k_merge_list_w, dim3(cw_blocks(std::max(cc, cl))), dim3(64), 0, sm, mw, chain(2));
             else hipLaunchKernelGGL(k_merge_list, dim3(1), dim3(1024), 0, sm, mw);
             hipLaunchKernelGGL(k_sort_tiles, dim3(padded / SORT_TILE), dim3(1024), 0, sm, mw);
+            // (the pool's size is on the device: the run length is chosen for the size the last collected frame suggests)
+            const int Ld = sort_decide_run(std::min<long>(pw, (long)nL_hint + nC_hint + VO_FRAME_MAX_PENDING * o.sel.keep));
             int from = 0;
-            for (int L = SORT_TILE; L < padded; L <<= 1, from ^= 1)
+            for (int L = SORT_TILE; L < Ld && L < padded; L <<= 1, from ^= 1)
                 hipLaunchKernelGGL(k_sort_merge, dim3(blocks(padded)), dim3(256), 0, sm, mw, L, from);
-            hipLaunchKernelGGL(k_sort_ranks, dim3(blocks(pw)), dim3(256), 0, sm, mw, from);
+            hipLaunchKernelGGL(k_sort_decide, dim3(blocks(padded, 64)), dim3(64), 0, sm, mw, Ld, from);
             if (wide) {
                 hipLaunchKernelGGL(k_merge_write_w, dim3(cw_blocks(std::max(cc, cl))), dim3(64), 0, sm, mw, chain(3));
                 const Chain cha = chain(4), chb = chain(5);
@@ -1290,10 +1437,11 @@ int vo_dev_merge_ranks(vo_ctx* ctx, const double* d_values, int n0, int np, int 
     mw.pool = const_cast<double*>(d_values); mw.surv = d_survives; mw.acc = d_accepted; mw.padded = padded;
     hipStream_t sm = ctx->stream;
     hipLaunchKernelGGL(k_sort_tiles, dim3(padded / SORT_TILE), dim3(1024), 0, sm, mw);
+    const int Ld = sort_decide_run(P);
     int from = 0;
-    for (int L = SORT_TILE; L < padded; L <<= 1, from ^= 1)
+    for (int L = SORT_TILE; L < Ld; L <<= 1, from ^= 1)
         hipLaunchKernelGGL(k_sort_merge, dim3(blocks(padded)), dim3(256), 0, sm, mw, L, from);
-    hipLaunchKernelGGL(k_sort_ranks, dim3(blocks((int)P)), dim3(256), 0, sm, mw, from);
+    hipLaunchKernelGGL(k_sort_decide, dim3(blocks(padded, 64)), dim3(64), 0, sm, mw, Ld, from);
     ST_CHECK(hipGetLastError());
     ST_CHECK(hipStreamSynchronize(sm));   // hn lives on this frame of the stack
     return VO_OK;
