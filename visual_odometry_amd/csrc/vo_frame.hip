@@ -869,6 +869,8 @@ struct vo_frame_state {
     bool overlap = true;                    // VO_FRAME_SERIAL=1: both branches on the ctx stream
     bool narrow = false;                    // VO_FRAME_NARROW=1: one-block compactions at every size (A/B switch, read at create)
     bool tracks_together = false;           // VO_FRAME_TRACKS_TOGETHER=1: both tracking launches start together at every size
+    int wide_min = 2048;                    // capacities beyond which the one-wave compactions run (VO_FRAME_WIDE_MIN: A/B switch)
+    int one_block = MERGE_ONE_BLOCK;        // pools up to which the one-block merge runs (VO_FRAME_ONE_BLOCK: A/B switch)
     hipEvent_t ev_rec[VO_FRAME_MAX_PENDING] = {};
     long long* h_stamps = nullptr;          // VO_FRAME_STAMPS=<file>: device clock at 16 points of each frame (diagnosis only)
     std::string stamp_path;
@@ -986,6 +988,8 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     st->overlap = !getenv("VO_FRAME_SERIAL");
     st->narrow = getenv("VO_FRAME_NARROW") != nullptr;
     st->tracks_together = getenv("VO_FRAME_TRACKS_TOGETHER") != nullptr;
+    if (const char* wm = getenv("VO_FRAME_WIDE_MIN")) st->wide_min = atoi(wm);
+    if (const char* ob = getenv("VO_FRAME_ONE_BLOCK")) st->one_block = atoi(ob);
     if (const char* sp = getenv("VO_FRAME_STAMPS")) {
         st->stamp_path = sp;
         if (const char* mk = getenv("VO_FRAME_STAMP_MASK")) st->stamp_mask = (unsigned)strtoul(mk, nullptr, 0);
@@ -1243,7 +1247,7 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     }
     auto leave_lane = [&]() { ctx->stream = sm; ctx->in_lane = false; };
     // large states: the ordered compactions as launches of one-wave workgroups (compact_wave) instead of one block each
-    const bool wide = (cl > 2048 || cc > 2048) && cw_blocks(pw) <= CW_MAX_BLOCKS && !st->narrow;
+    const bool wide = (cl > st->wide_min || cc > st->wide_min) && cw_blocks(pw) <= CW_MAX_BLOCKS && !st->narrow;
     auto chain = [&](int site) {
         if (++st->chain_epoch == 0) ++st->chain_epoch;     // 0 is what a never-written word holds
         return Chain{st->chain + (size_t)site * CW_MAX_BLOCKS, st->chain_epoch};
@@ -1328,7 +1332,7 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
         // landmarks the next frame starts from (st->sizes[0])
         CandOp cop = {ca, cc, st->cq, st->cf[s], st->cpose[s], st->ctime[s], st->cu[n], st->cf[n], st->cpose[n], st->ctime[n]};
         LandmarkOp lop = {st->alive, pw, cl, st->wkp, st->wL, st->wrep, st->kp[n], st->L[n], st->rep[n]};
-        if (pw <= MERGE_LDS && nL_hint + nC_hint + VO_FRAME_MAX_PENDING * o.sel.keep <= MERGE_ONE_BLOCK) {
+        if (pw <= MERGE_LDS && nL_hint + nC_hint + VO_FRAME_MAX_PENDING * o.sel.keep <= st->one_block) {
             hipLaunchKernelGGL(k_merge_par, dim3(2), dim3(1024), 0, sm, m, cop, cc, counts + 1, lop, counts + 0, st->sizes);
         } else {                                               // the all-pairs counts spread over the chip
             const int padded = st->sort_padded;
