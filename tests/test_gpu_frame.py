@@ -150,7 +150,7 @@ def test_device_images_and_kitti_shape(ctx):
 def test_merge_beyond_the_lds_copies(ctx, sequence):
     """2600 promotable candidates against a landmark cap of 5000 + 3000 candidates (a pool beyond the one-block
     merge's 4096 LDS entries), then against a cap of 150, where almost every one replaces the worst landmark:
-    both through the sort-based merge (list, tile sort, merge levels, ranks, ordered write), the second as one-block
+    both through the sort-based merge (list, tile sort, the decisions from the sorted runs, ordered write), the second as one-block
     compactions around it (a state below 2048 entries), the first as one-wave compactions."""
     frames, poses, lift = sequence
     k = 8

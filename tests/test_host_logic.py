@@ -168,7 +168,7 @@ def test_merge_policy_closed_form_equals_the_sequential_loop():
 
 
 def test_sort_based_merge_equals_the_sequential_loop_on_tie_heavy_pools():
-    """The device merge for LARGE pools (round 3: k_sort_tiles / k_sort_merge / k_sort_ranks, vo_frame.hip) takes both
+    """The device merge for LARGE pools (round 3: k_sort_tiles / k_sort_decide, vo_frame.hip) takes both
     decisions from one stable merge sort by reproError: `before` = the strictly smaller keys of the left-hand runs an
     entry is merged with, level by level; `rank` = the sorted position mirrored inside its group of equal keys.  The
     same steps in numpy (same run structure, same binary searches, a padded tail of +inf keys, partner runs shorter
