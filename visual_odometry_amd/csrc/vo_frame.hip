@@ -516,20 +516,6 @@ __device__ __forceinline__ int bound(Ptr key, int lo, int hi, double v) {
     }
     return lo;
 }
-// one merge step for the element at sorted position p of a run of length L: where it goes in the merged run of 2 L,
-// and (right-hand runs) how many keys of the left-hand run are strictly smaller
-template <class Ptr>
-__device__ __forceinline__ int merge_place(Ptr key, int p, int L, double v, int* smaller_left) {
-    const int run = p / L, base = (run >> 1) * 2 * L;
-    if (run & 1) {   // right-hand run: behind the left keys that are <= v (the left run holds the earlier pool entries)
-        const int le = bound<true>(key, base, base + L, v) - base;
-        *smaller_left = bound<false>(key, base, base + le, v) - base;
-        return base + (p - (base + L)) + le;
-    }
-    *smaller_left = 0;
-    return base + (p - base) + (bound<false>(key, base + L, base + 2 * L, v) - (base + L));   // behind the right keys that are < v
-}
-
 __global__ __launch_bounds__(1024) void k_sort_tiles(MergeWideArgs w) {
     __shared__ double s_key[2][SORT_TILE];
     __shared__ int32_t s_idx[2][SORT_TILE];
