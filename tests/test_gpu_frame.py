@@ -220,8 +220,8 @@ def test_merge_at_the_stress_size(ctx):
 @pytest.mark.parametrize("depth", [1, 2])
 def test_large_states_take_one_wave_compactions_with_the_same_bits(ctx, depth, monkeypatch):
     """States beyond 2048 entries run their ordered compactions as launches of one-wave workgroups that publish their
-    counts (compact_wave; k_tracked_w, k_pose_tail_w, k_merge_list_w, k_merge_write_w, k_compact2_w) and start the
-    candidates' tracking launch behind the landmarks'.  A chain of frames on a KITTI-shaped sequence -- 3000 landmarks at
+    counts (compact_wave; k_tracked_w, k_pose_tail_w, k_merge_list_w, k_merge_write_w, k_compact2_w) and -- from 32k
+    keypoints a frame, here from 1000 (VO_FRAME_L_FIRST_MIN) -- start the candidates' tracking launch behind the landmarks'.  A chain of frames on a KITTI-shaped sequence -- 3000 landmarks at
     the cap, 3000 seeded candidates of which a few hundred are promoted a frame, new candidates every frame, the
     look-ahead on -- gives the bits of the one-block kernels (VO_FRAME_NARROW=1, read when a loop is created), frame by frame
     and in the final state; and the first frame matches the oracle's restatement of processFrame."""
@@ -236,6 +236,8 @@ def test_large_states_take_one_wave_compactions_with_the_same_bits(ctx, depth, m
             monkeypatch.setenv("VO_FRAME_NARROW", "1")
         else:
             monkeypatch.delenv("VO_FRAME_NARROW", raising=False)
+        # the landmarks-first order of the two tracking launches starts at 32k keypoints a frame by itself: here from 1000
+        monkeypatch.setenv("VO_FRAME_L_FIRST_MIN", "1000")
         loop = FrameLoop(KK, frames[0].shape, ctx=ctx, **kw)
         loop.set_state(st0, frames[0])
         got, pending = [], 0
@@ -255,6 +257,7 @@ def test_large_states_take_one_wave_compactions_with_the_same_bits(ctx, depth, m
     wide, wide_final = run(False)
     narrow, narrow_final = run(True)
     monkeypatch.delenv("VO_FRAME_NARROW", raising=False)
+    monkeypatch.delenv("VO_FRAME_L_FIRST_MIN", raising=False)
     assert sum(i["n_promoted"] for _, _, i in wide) > 500 and sum(i["n_new"] for _, _, i in wide) > 500
     for (p0, s0, i0), (p1, s1, i1) in zip(wide, narrow):
         assert np.array_equal(p0, p1) and s0 == s1 and i0 == i1

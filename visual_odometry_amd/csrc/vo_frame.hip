@@ -857,6 +857,7 @@ struct vo_frame_state {
     bool tracks_together = false;           // VO_FRAME_TRACKS_TOGETHER=1: both tracking launches start together at every size
     int wide_min = 2048;                    // capacities beyond which the one-wave compactions run (VO_FRAME_WIDE_MIN: A/B switch)
     int one_block = MERGE_ONE_BLOCK;        // pools up to which the one-block merge runs (VO_FRAME_ONE_BLOCK: A/B switch)
+    int l_first_min = 32768;                // keypoints of a frame from which the landmarks' launch goes first (VO_FRAME_L_FIRST_MIN)
     hipEvent_t ev_rec[VO_FRAME_MAX_PENDING] = {};
     long long* h_stamps = nullptr;          // VO_FRAME_STAMPS=<file>: device clock at 16 points of each frame (diagnosis only)
     std::string stamp_path;
@@ -976,6 +977,7 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     st->tracks_together = getenv("VO_FRAME_TRACKS_TOGETHER") != nullptr;
     if (const char* wm = getenv("VO_FRAME_WIDE_MIN")) st->wide_min = atoi(wm);
     if (const char* ob = getenv("VO_FRAME_ONE_BLOCK")) st->one_block = atoi(ob);
+    if (const char* lf = getenv("VO_FRAME_L_FIRST_MIN")) st->l_first_min = atoi(lf);
     if (const char* sp = getenv("VO_FRAME_STAMPS")) {
         st->stamp_path = sp;
         if (const char* mk = getenv("VO_FRAME_STAMP_MASK")) st->stamp_mask = (unsigned)strtoul(mk, nullptr, 0);
@@ -1250,7 +1252,11 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     // Large states: two tracking launches that start together share the chip and end together, and the pose chain -- the
     // frame's critical path -- starts when both are done.  The candidates' launch starts behind the landmarks' instead (it
     // is needed from the triangulation on) and runs beside the pose chain, whose one-wave kernels take the holes it leaves.
-    const bool l_first = wide && sl != sm && !st->tracks_together;
+    // From about 32k keypoints a frame, that is: measured with as many seeded candidates as landmarks, the two orders are
+    // equal at 20k + 13k keypoints (0.696 ms per frame either way), landmarks first wins at 24k + 21k (0.807 against 0.836)
+    // and loses below (16k + 7k: 0.600 against 0.584; 8k + 8k: 0.401 against 0.369) -- two launches that do not fill the
+    // chip several times over lose more by running one after the other than the pose chain gains by starting early.
+    const bool l_first = wide && sl != sm && !st->tracks_together && nL_hint + nC_hint >= st->l_first_min;
     if (l_first) ST_CHECK(hipEventRecord(st->ev_ltrack, sl));
     stamp(sl, 1);
     {   // (the frame's counters and tombstones are cleared by the same launch)
