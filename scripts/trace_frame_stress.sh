@@ -1,11 +1,11 @@
 #!/bin/bash
 # kernel trace of the frame loop at the stress size, and the timeline of one steady-state frame:
-#   bash scripts/trace_frame_stress.sh        outputs under gpurun_out/frame_stress/
+#   bash scripts/trace_frame_stress.sh [frame_stress.py options]       outputs under gpurun_out/frame_stress/
 set -e
 R=$PWD; O=$R/gpurun_out/frame_stress; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/repo_prof && cp -r $R /tmp/repo_prof && cd /tmp/repo_prof
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -- python3 scripts/frame_stress.py --passes 3 > $O/run.log 2> $O/trace.log
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/t -- python3 scripts/frame_stress.py --passes 3 "$@" > $O/run.log 2> $O/trace.log
 cp $(find $O/t -name "*kernel_stats.csv") $O/kernel_stats.csv
 python3 - "$(find $O/t -name '*kernel_trace.csv' | head -1)" > $O/timeline.txt <<'PY'
 import csv, sys, re
