@@ -102,6 +102,40 @@ def test_empty_and_tiny_states(ctx, sequence):
     loop.close()
 
 
+def test_empty_large_state_does_not_wait_for_a_head_that_never_comes(ctx, sequence, monkeypatch):
+    """Large states start the candidates' tracking launch behind a HEAD of the landmarks' launch (a count of finished
+    workgroups and a flag, polled by a one-lane kernel).  A state without a landmark has no workgroup that could arrive:
+    the polling kernel reads the count on the device and returns at once instead of running into its time-out."""
+    import ctypes as C
+    import time
+    frames, _, lift = sequence
+    monkeypatch.setenv("VO_FRAME_L_FIRST_MIN", "0")
+    loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=3000, maxCandidates=3000, CandidatesToKeep=40, ctx=ctx)
+    monkeypatch.delenv("VO_FRAME_L_FIRST_MIN", raising=False)
+    loop.set_state(vo_frame.new_state(), frames[0])
+    loop.processFrame(frames[1])                          # buffers, code objects
+    loop.set_state(vo_frame.new_state(), frames[0])
+    ctx.sync()
+    t0 = time.perf_counter()
+    pose, status, info = loop.processFrame(frames[1])
+    dt = time.perf_counter() - t0
+    t = C.c_int(-1)
+    ctx.call("vo_dev_head_timed_out", C.byref(t))
+    assert status == 1 and info["n_landmarks"] == 0 and info["n_new"] == 40
+    assert t.value == 0 and dt < 0.1, (t.value, dt)
+    # ... and with landmarks the order gives the frame of the other order
+    st = start_state(frames[0], lift, n=140)
+    loop.set_state(st, frames[0])
+    p1, s1, i1 = loop.processFrame(frames[1])
+    g1 = loop.get_state()
+    loop.close()
+    loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=3000, maxCandidates=3000, CandidatesToKeep=40, ctx=ctx)
+    loop.set_state(st, frames[0])
+    p2, s2, i2 = loop.processFrame(frames[1])
+    assert s1 == s2 == 0 and np.array_equal(p1, p2) and i1 == i2 and states_equal(g1, loop.get_state())
+    loop.close()
+
+
 def test_candidate_capacity_overflow_is_flagged(ctx, sequence):
     frames, _, lift = sequence
     loop = FrameLoop(K, frames[0].shape, maxNumLandmarks=200, maxCandidates=130, ctx=ctx)

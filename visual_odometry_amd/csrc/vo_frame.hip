@@ -858,6 +858,7 @@ struct vo_frame_state {
     int wide_min = 2048;                    // capacities beyond which the one-wave compactions run (VO_FRAME_WIDE_MIN: A/B switch)
     int one_block = MERGE_ONE_BLOCK;        // pools up to which the one-block merge runs (VO_FRAME_ONE_BLOCK: A/B switch)
     int l_first_min = 32768;                // keypoints of a frame from which the landmarks' launch goes first (VO_FRAME_L_FIRST_MIN)
+    int l_head_pct = 85;                    // ... and the share of it behind which the candidates' launch starts (VO_FRAME_L_HEAD_PCT; 100: its end, an event)
     hipEvent_t ev_rec[VO_FRAME_MAX_PENDING] = {};
     long long* h_stamps = nullptr;          // VO_FRAME_STAMPS=<file>: device clock at 16 points of each frame (diagnosis only)
     std::string stamp_path;
@@ -978,6 +979,7 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     if (const char* wm = getenv("VO_FRAME_WIDE_MIN")) st->wide_min = atoi(wm);
     if (const char* ob = getenv("VO_FRAME_ONE_BLOCK")) st->one_block = atoi(ob);
     if (const char* lf = getenv("VO_FRAME_L_FIRST_MIN")) st->l_first_min = atoi(lf);
+    if (const char* lh = getenv("VO_FRAME_L_HEAD_PCT")) st->l_head_pct = std::min(100, std::max(1, atoi(lh)));
     if (const char* sp = getenv("VO_FRAME_STAMPS")) {
         st->stamp_path = sp;
         if (const char* mk = getenv("VO_FRAME_STAMP_MASK")) st->stamp_mask = (unsigned)strtoul(mk, nullptr, 0);
@@ -1247,8 +1249,12 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     // [1] :278-281 track the landmarks' keypoints (read straight from the state) and keep the validly tracked ones in
     // order.  The number M of those stays on the device (counts[6]): the pose step, the reprojection filter and the
     // compaction are sized by the capacity and read M themselves.
+    const bool l_first = wide && sl != sm && !st->tracks_together && nL_hint + nC_hint >= st->l_first_min;
+    // (landmarks first, below: the candidates' launch starts when the first l_head_pct % of the landmarks are out)
+    const int l_head = l_first && st->l_head_pct < 100 ? std::max(1, (int)((long)std::min(cl, std::max(nL_hint, 1)) * st->l_head_pct / 100)) : 0;
     if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->kp[s], st->kp[s] + cl, cl, o.klt.block_w, o.klt.block_h,
-                            o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, /* scores: processFrame discards them, :278 */ nullptr, nullptr, st->sizes + 0))) { leave_lane(); return rc; }
+                            o.klt.max_iters, eps, o.klt.max_bidir_err, st->q, st->q + pw, st->valid, /* scores: processFrame discards them, :278 */ nullptr, nullptr, st->sizes + 0,
+                            l_head))) { leave_lane(); return rc; }
     // Large states: two tracking launches that start together share the chip and end together, and the pose chain -- the
     // frame's critical path -- starts when both are done.  The candidates' launch starts behind the landmarks' instead (it
     // is needed from the triangulation on) and runs beside the pose chain, whose one-wave kernels take the holes it leaves.
@@ -1256,8 +1262,7 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     // equal at 20k + 13k keypoints (0.696 ms per frame either way), landmarks first wins at 24k + 21k (0.807 against 0.836)
     // and loses below (16k + 7k: 0.600 against 0.584; 8k + 8k: 0.401 against 0.369) -- two launches that do not fill the
     // chip several times over lose more by running one after the other than the pose chain gains by starting early.
-    const bool l_first = wide && sl != sm && !st->tracks_together && nL_hint + nC_hint >= st->l_first_min;
-    if (l_first) ST_CHECK(hipEventRecord(st->ev_ltrack, sl));
+    if (l_first && st->l_head_pct >= 100) ST_CHECK(hipEventRecord(st->ev_ltrack, sl));
     stamp(sl, 1);
     {   // (the frame's counters and tombstones are cleared by the same launch)
         TrackedOp top = {st->valid, st->q, st->q + pw, st->L[s], cl, st->vk, st->vl};
@@ -1300,7 +1305,10 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     if (st->next_src) ST_CHECK(hipEventRecord(st->ev_fork_la, sm));
     stamp(sm, 5);
     // :71 track the candidates: points from the state, results straight into the candidates' work arrays
-    if (l_first) ST_CHECK(hipStreamWaitEvent(sm, st->ev_ltrack, 0));
+    if (l_first) {
+        if (st->l_head_pct >= 100) ST_CHECK(hipStreamWaitEvent(sm, st->ev_ltrack, 0));
+        else if ((rc = vo_launch_wait_head(ctx, st->sizes + 0))) return rc;      // (ctx->stream is sm again)
+    }
     if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->cu[s], st->cu[s] + cc, cc, o.klt.block_w, o.klt.block_h,
                             o.klt.max_iters, eps, o.klt.max_bidir_err, st->cq, st->cq + cc, st->cvalid, /* :71 `~` */ nullptr, nullptr, st->sizes + 1))) return rc;
     stamp(sm, 6);

@@ -675,8 +675,9 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
 // The consumers' side of a head (vo_dev_wait_head): one lane polls the flag until the launch's epoch is there.  Bounded:
 // after ~0.25 s of polling it gives up and raises *timed_out (the launch it waits for was never enqueued, or sits behind
 // this kernel in the same hardware queue) -- every wave of this kernel reaches its end whatever happens.
-__global__ __launch_bounds__(64) void k_wait_head(const unsigned* flag, unsigned epoch, unsigned* timed_out) {
+__global__ __launch_bounds__(64) void k_wait_head(const unsigned* flag, unsigned epoch, unsigned* timed_out, const int32_t* n_dev) {
     if (threadIdx.x != 0) return;
+    if (n_dev && *n_dev <= 0) return;   // the launch had no keypoint at all (its count lives on the device): nobody arrives
     for (int spin = 0; spin < 250000; ++spin) {
         const unsigned f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((int)(f - epoch) >= 0) return;
@@ -699,9 +700,9 @@ void launch(const LKArgs& a, hipStream_t st) {
 
 } // namespace
 
-int vo_launch_wait_head(vo_ctx* ctx) {
+int vo_launch_wait_head(vo_ctx* ctx, const int32_t* d_n) {
     unsigned* w = reinterpret_cast<unsigned*>(vo_int_head_words(ctx));
-    hipLaunchKernelGGL(k_wait_head, dim3(1), dim3(64), 0, ctx->stream, w + 1, ctx->head_epoch, w + 2);
+    hipLaunchKernelGGL(k_wait_head, dim3(1), dim3(64), 0, ctx->stream, w + 1, ctx->head_epoch, w + 2, d_n);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }
