@@ -280,3 +280,39 @@ def essential_ransac(p0, p1, K, num_hyp=2000, max_distance=0.09, confidence=0.99
     if want_all:
         out.update(counts=cnt, costs=cost, Es=Es)
     return out
+
+
+def philox_sample5(seed, hyp, m):
+    idx = np.zeros(5, np.int32)
+    lib().vo_or_philox_sample5(C.c_uint64(seed), C.c_uint32(hyp), C.c_uint32(m), _p(idx))
+    return idx
+
+
+def five_point(x0, x1):
+    """x0, x1: 5 x 2 K^-1-normalised points -> n x 3 x 3 matrices E (x1' E x0 = 0, singular values (1, 1, 0)), n <= 10,
+    ascending in the root of Nister's tenth-degree polynomial (N10b, oracle/five_point.c)."""
+    x0 = _c(x0, np.float64).reshape(5, 2); x1 = _c(x1, np.float64).reshape(5, 2)
+    a0 = np.ascontiguousarray(x0[:, 0]); b0 = np.ascontiguousarray(x0[:, 1])
+    a1 = np.ascontiguousarray(x1[:, 0]); b1 = np.ascontiguousarray(x1[:, 1])
+    Es = np.zeros((10, 3, 3))
+    n = lib().vo_or_five_point(_p(a0), _p(b0), _p(a1), _p(b1), _p(Es))
+    return Es[:n]
+
+
+def essential_ransac5(p0, p1, K, num_hyp=2000, max_distance=0.09, confidence=0.995, seed=1023, min_inliers=5,
+                      sample_idx=None, threads=1, want_all=False):
+    """modules/bootstrap.m:76-79 around the five-point solver (N10b, oracle/five_point.c); the per-hypothesis outputs
+    have 10 slots per sample and best_hyp is a slot index (10 h + s)."""
+    p0 = _c(p0, np.float64).reshape(-1, 2); p1 = _c(p1, np.float64).reshape(-1, 2); K = _c(K, np.float64)
+    m = p0.shape[0]
+    o = RansacOpts(num_hyp, max_distance, confidence, seed, 1, min_inliers, threads)
+    E = np.zeros((3, 3)); inl = np.zeros(max(m, 1), np.uint8)
+    bh = C.c_int(); used = C.c_int()
+    si = None if sample_idx is None else _c(sample_idx, np.int32)
+    cnt = np.zeros(10 * num_hyp, np.int32); cost = np.zeros(10 * num_hyp, np.uint64); Es = np.zeros((10 * num_hyp, 3, 3))
+    st = lib().vo_or_essential_ransac5(_p(p0), _p(p1), m, _p(K), C.byref(o), None if si is None else _p(si), _p(E), _p(inl),
+                                       C.byref(bh), C.byref(used), _p(cnt), _p(cost), _p(Es))
+    out = dict(status=st, E=E, inliers=inl[:m].astype(bool), best_hyp=bh.value, trials=used.value)
+    if want_all:
+        out.update(counts=cnt, costs=cost, Es=Es)
+    return out

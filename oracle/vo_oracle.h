@@ -68,6 +68,7 @@
  *                floor(thr^2 * 2^20) per outlier; see p3p.c.
  * N10 essential   bootstrap's estimateEssentialMatrix: MSAC around the normalised eight-point algorithm,
  *                Sampson distance in pixels^2, Philox samples of 8; see essential.c.
+ * N10b            the same around Nister's five-point solver (samples of 5, up to ten matrices each); see five_point.c.
  */
 #ifndef VO_ORACLE_H
 #define VO_ORACLE_H
@@ -176,6 +177,14 @@ int vo_or_essential_ransac(const double* p0, const double* p1, int m, const doub
                            const vo_or_ransac_opts* o, const int32_t* sample_idx, double* E,
                            uint8_t* inliers, int* best_hyp, int* trials_used, int32_t* hyp_count,
                            uint64_t* hyp_cost, double* hyp_E /* H x 9 */);
+/* N10b (five_point.c): the same step around Nister's five-point solver.  Es: up to 10 matrices per sample, ascending
+ * in the root; the hyp_* arrays of the loop have 10 slots per sample and best_hyp is a slot index (10 h + s). */
+void vo_or_philox_sample5(uint64_t seed, uint32_t hyp, uint32_t m, int32_t* idx5);
+int vo_or_five_point(const double* x0, const double* y0, const double* x1, const double* y1, double* Es /* 10 x 9 */);
+int vo_or_essential_ransac5(const double* p0, const double* p1, int m, const double* K,
+                            const vo_or_ransac_opts* o, const int32_t* sample_idx, double* E,
+                            uint8_t* inliers, int* best_hyp, int* trials_used, int32_t* hyp_count,
+                            uint64_t* hyp_cost, double* hyp_E);
 
 #ifdef __cplusplus
 }
