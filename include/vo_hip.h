@@ -231,6 +231,16 @@ int vo_essential_ransac(vo_ctx* ctx, vo_layout lay, const double* pts0, const do
                         const vo_ransac_opts* opts, const int32_t* sample_idx, const double* hyp_E_in, double* out_E,
                         uint8_t* out_inliers, vo_ransac_info* info, int32_t* hyp_counts, uint64_t* hyp_costs,
                         double* hyp_E_out);
+/* The same step around a FIVE-POINT solver (D. Nister, PAMI 26(6), 2004), the kind of solver the toolbox function
+ * wraps -- modules/bootstrap.m:76-79; definition N10b, oracle/five_point.c.  Unlike the eight-point algorithm it
+ * works on planar scenes.  A sample of five correspondences gives up to ten matrices, each scored; the adaptive stop
+ * counts samples (N = log(1 - p) / log(1 - w^5)).  info->status 1: fewer than 5 correspondences.  sample_idx
+ * (optional) H x 5.  The inspection outputs have TEN slots per sample (10 H counts / costs, 10 H x 9 matrices; unused
+ * slots: count 0, the cost of M outliers, E = 0) and info->best_hyp is a slot index (10 h + s); info->trials_used counts
+ * samples. */
+int vo_essential_ransac_five(vo_ctx* ctx, vo_layout lay, const double* pts0, const double* pts1, int M, const double* K,
+                             const vo_ransac_opts* opts, const int32_t* sample_idx, double* out_E, uint8_t* out_inliers,
+                             vo_ransac_info* info, int32_t* hyp_counts, uint64_t* hyp_costs, double* hyp_E_out);
 
 /* ==== device-pointer entry points (inputs/outputs resident in HBM; asynchronous on the ctx
  * stream).  Internal convention: image = nv rows of nu contiguous bytes, (u,v) zero-based;

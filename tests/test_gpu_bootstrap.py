@@ -107,3 +107,61 @@ def test_bootstrap_matches_the_oracle_and_feeds_the_frame_loop(ctx):
         assert cosang > 0.8 and 0.5 < np.linalg.norm(c_est) / np.linalg.norm(c_true) < 2.0
         assert np.abs(p[:3] - poses[k][:3]).max() < 0.08
     loop.close()
+
+
+def planar_two_view_points(n=2000, seed=8, outliers=0.25, noise=0.05):
+    """points on a slanted plane (the road in front of a car): the scene the eight-point algorithm cannot do"""
+    rng = np.random.default_rng(seed)
+    x, y = rng.uniform(-15, 15, n), rng.uniform(-4, 4, n)
+    X = np.stack([x, y, 25 + 0.4 * x - 0.8 * y], 1)
+    R, C = synth.rot_y(2.0), np.array([0.8, 0.05, 0.3])
+    p0, _ = synth.project(synth.KITTI_K, np.eye(3), np.zeros(3), X)
+    p1, _ = synth.project(synth.KITTI_K, R, C, X)
+    p0 = p0 + rng.normal(0, noise, p0.shape); p1 = p1 + rng.normal(0, noise, p1.shape)
+    out = rng.random(n) < outliers
+    p1[out] += rng.uniform(-30, 30, (int(out.sum()), 2))
+    return p0, p1, out, R, C
+
+
+@pytest.mark.parametrize("confidence", [0.0, 0.995])
+@pytest.mark.parametrize("scene", ["general", "planar"])
+def test_five_point_msac_equals_the_oracle(ctx, scene, confidence):
+    """Nister's five-point solver on the device against oracle/five_point.c (N10b): the same operations in the same order,
+    sqrt and division only, so every solution of every sample, every count and cost, the record, the number of samples
+    used and the inlier set agree bit for bit -- on the seeded stream and from a table of samples."""
+    p0, p1, out, R, C = two_view_points(n=1500, seed=6) if scene == "general" else planar_two_view_points()
+    o = oracle.essential_ransac5(p0, p1, synth.KITTI_K, num_hyp=300, confidence=confidence, seed=31, threads=8, want_all=True)
+    g = ops.essential_ransac_five(p0, p1, synth.KITTI_K, num_hyp=300, confidence=confidence, seed=31, want_all=True)
+    same = (g["Es"] == o["Es"]).all(axis=(1, 2))
+    assert same.mean() > 0.99 and np.abs(g["Es"] - o["Es"]).max() < 1e-9, (same.mean(), np.abs(g["Es"] - o["Es"]).max())
+    np.testing.assert_array_equal(g["counts"][same], o["counts"][same])
+    np.testing.assert_array_equal(g["costs"][same], o["costs"][same])
+    assert g["status"] == o["status"] == 0 and g["best_hyp"] == o["best_hyp"] and g["trials"] == o["trials"]
+    np.testing.assert_array_equal(g["E"], o["E"])
+    np.testing.assert_array_equal(g["inliers"], o["inliers"])
+    assert g["num_inliers"] == o["inliers"].sum() and (g["inliers"] & out).mean() < 0.01 and g["inliers"][~out].mean() > 0.9
+    if confidence > 0:
+        assert g["trials"] < 300
+    nsol = (g["Es"].reshape(300, 10, 9) != 0).any(axis=2).sum(axis=1)
+    assert nsol.max() <= 10 and nsol.mean() > 2
+    idx = np.stack([oracle.philox_sample5(31, h, len(p0)) for h in range(300)])
+    g2 = ops.essential_ransac_five(p0, p1, synth.KITTI_K, num_hyp=300, confidence=confidence, sample_idx=idx, want_all=True)
+    np.testing.assert_array_equal(g2["Es"], g["Es"])
+    np.testing.assert_array_equal(g2["costs"], g["costs"])
+    if scene == "general":
+        t = -R @ C
+        Et = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+        Et *= np.sqrt(2) / np.linalg.norm(Et)
+        assert min(np.abs(g["E"] - Et).max(), np.abs(g["E"] + Et).max()) < 0.2
+
+
+def test_five_point_statuses(ctx):
+    p0, p1, *_ = two_view_points(n=40, outliers=0.0)
+    r = ops.essential_ransac_five(p0[:4], p1[:4], synth.KITTI_K, num_hyp=10)
+    assert r["status"] == 1 and not r["inliers"].any() and not r["E"].any()           # fewer than 5 correspondences
+    r = ops.essential_ransac_five(p0[:5], p1[:5], synth.KITTI_K, num_hyp=10)
+    assert r["status"] == 0 and r["inliers"].all()                                    # exactly one sample's worth
+    junk = np.random.default_rng(0).uniform(0, 300, (40, 2))
+    r = ops.essential_ransac_five(p0, junk, synth.KITTI_K, num_hyp=50, min_inliers=30)
+    o = oracle.essential_ransac5(p0, junk, synth.KITTI_K, num_hyp=50, min_inliers=30)
+    assert r["status"] == o["status"] == 2

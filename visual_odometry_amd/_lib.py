@@ -66,7 +66,7 @@ EXPORTS = [
     "vo_timer_lap_begin", "vo_timer_lap_end", "vo_timer_laps_ms", "vo_ctx_time_score", "vo_ctx_read_score_tests",
     "vo_klt_track", "vo_select_candidates", "vo_harris_response", "vo_corner_response",
     "vo_select_keypoints_greedy", "vo_triangulate_candidates", "vo_angle_deg", "vo_in_front", "vo_reproj_error",
-    "vo_p3p_ransac", "vo_p3p_batch", "vo_essential_ransac", "vo_dev_frame_build", "vo_dev_klt_track", "vo_dev_klt_track_head", "vo_dev_wait_head", "vo_dev_head_timed_out", "vo_dev_select_candidates", "vo_dev_select_begin", "vo_dev_select_finish",
+    "vo_p3p_ransac", "vo_p3p_batch", "vo_essential_ransac", "vo_essential_ransac_five", "vo_dev_frame_build", "vo_dev_klt_track", "vo_dev_klt_track_head", "vo_dev_wait_head", "vo_dev_head_timed_out", "vo_dev_select_candidates", "vo_dev_select_begin", "vo_dev_select_finish",
     "vo_dev_frame_prefetch",
     "vo_dev_triangulate", "vo_dev_p3p_ransac", "vo_dev_p3p_ransac_static", "vo_dev_merge_ranks", "vo_frame_create", "vo_frame_destroy", "vo_frame_set_state",
     "vo_frame_get_counts", "vo_frame_get_state", "vo_frame_set_image", "vo_frame_process", "vo_frame_submit", "vo_frame_collect", "vo_frame_announce",

@@ -173,7 +173,7 @@ int vo_launch_ransac(vo_ctx* ctx, const double* d_xy, vo_strides sxy, const doub
                      double* d_pose_out = nullptr);   // optional: the winning pose as [R_WC; t_WC], written by the last kernel
 int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_strides sp, int M, const double* d_K,
                         const vo_ransac_opts* o, const int32_t* d_sample_idx, const double* d_E_in, vo_ransac_work* w,
-                        void* d_out, uint8_t* d_inliers);
+                        void* d_out, uint8_t* d_inliers, int solver = 8);
 int vo_static_scratch_resolve(int device);   // vo_ransac.hip: address of this device's copy of the static work array
 int vo_launch_p3p_batch(vo_ctx* ctx, const double* d_P, const double* d_f, int n, double* d_poses);
 

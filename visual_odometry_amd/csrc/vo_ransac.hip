@@ -575,6 +575,7 @@ __device__ __forceinline__ double ransac_limit(double confidence, int bcnt, int 
     double wi = 1.0 - orat;
     double wk;
     if (sample_size == 8) { const double w2 = wi * wi, w4 = w2 * w2; wk = w4 * w4; } // essential.c
+    else if (sample_size == 5) { const double w2 = wi * wi, w4 = w2 * w2; wk = w4 * wi; } // five_point.c
     else wk = wi * wi * wi;                                                            // old/ransacLocalization.m:121
     return log(1.0 - confidence) / log(1.0 - wk);
 }
@@ -582,7 +583,8 @@ __device__ __forceinline__ double ransac_limit(double confidence, int bcnt, int 
 struct BestArgs {
     const int32_t* cnt; const unsigned long long* cost; const double* Rt; int H, M, mode, min_inl;
     double confidence; double* out; // R_cw(9) t_cw(3) then 6 int32: status, hyp, sol, trials, inliers, stopped
-    int sample_size;                // 3 (P3P) or 8 (eight-point)
+    int sample_size;                // 3 (P3P), 8 (eight-point) or 5 (five-point)
+    int rows_per_trial = 1;         // five-point: a sample's ten solutions are ten rows of the table; the stop is tested once per sample
     int later_stage;                // 1: an earlier stage ran on a prefix; keep its record if it reached the stop
     const int32_t* M_dev;           // as in HypArgs; fewer than 4 points: status 1 and the identity
     unsigned long long* bound_out;  // non-null (first stage): the record's cost / count for k_score's early out
@@ -665,7 +667,9 @@ __device__ __forceinline__ void best_body(BestArgs a) {
                 cur.h = h; cur.s = s; cur.c = c; cur.q = q;
                 N = ransac_limit(a.confidence, cur.c, a.M, a.sample_size);
             }
-            if (!(N > (double)(h + 2))) { stop = h; break; } // :44 `while num_iterations > i`
+            if (a.rows_per_trial == 1) {
+                if (!(N > (double)(h + 2))) { stop = h; break; } // :44 `while num_iterations > i`
+            } else if (h % a.rows_per_trial == a.rows_per_trial - 1 && !(N > (double)(h / a.rows_per_trial + 2))) { stop = h; break; }
         }
         if (stop != 0x7fffffff) atomicMin(&s_stop, stop);
     }
@@ -679,7 +683,7 @@ __device__ __forceinline__ void best_body(BestArgs a) {
     if (tid == 0) {
         const BState fin = s_fin;
         int32_t* info = (int32_t*)(a.out + 12);
-        const int used = gstop == 0x7fffffff ? a.H : gstop + 1;
+        const int used = (gstop == 0x7fffffff ? a.H : gstop + 1) / a.rows_per_trial;
         if (fin.h >= 0) {
             const double* p = a.Rt + 48 * (long)fin.h + 12 * fin.s;
             for (int k = 0; k < 12; ++k) a.out[k] = p[k];
@@ -1161,6 +1165,216 @@ __global__ __launch_bounds__(64) void k_e_hyp(EHypArgs a) {
     for (int k = 9; k < 48; ++k) o[k] = 0.0;
 }
 
+// ---- Nister's five-point solver (definition N10b, oracle/five_point.c: the same operations in the same order) ----
+__device__ void philox_sample5(uint64_t seed, uint32_t hyp, uint32_t m, int32_t* idx) {
+    uint32_t r[8], c[4], key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    c[0] = hyp; c[1] = 0; c[2] = 0; c[3] = 0; philox4x32_10(c, key); for (int k = 0; k < 4; ++k) r[k] = c[k];
+    c[0] = hyp; c[1] = 1; c[2] = 0; c[3] = 0; philox4x32_10(c, key); for (int k = 0; k < 4; ++k) r[4 + k] = c[k];
+    uint32_t sorted[5];
+    for (int j = 0; j < 5; ++j) {
+        uint32_t v = r[j] % (m - (uint32_t)j);
+        for (int k = 0; k < j; ++k)
+            if (v >= sorted[k]) ++v;
+        int pos = j;
+        while (pos > 0 && sorted[pos - 1] > v) { sorted[pos] = sorted[pos - 1]; --pos; }
+        sorted[pos] = v;
+        idx[j] = (int32_t)v;
+    }
+}
+// monomials.  degree <= 1: [x y z 1]; degree <= 2: [x^2 xy xz y^2 yz z^2 x y z 1]; degree <= 3: Nister's order
+// [x^3 y^3 x^2y xy^2 x^2z x^2 y^2z y^2 xyz xy | xz^2 xz x yz^2 yz y z^3 z^2 z 1]
+__device__ const int FP_M11[4][4] = {{0, 1, 2, 6}, {1, 3, 4, 7}, {2, 4, 5, 8}, {6, 7, 8, 9}};
+__device__ const int FP_M21[10][4] = {{0, 2, 4, 5}, {2, 3, 8, 9}, {4, 8, 10, 11}, {3, 1, 6, 7}, {8, 6, 13, 14},
+                                      {10, 13, 16, 17}, {5, 9, 11, 12}, {9, 7, 14, 15}, {11, 14, 17, 18}, {12, 15, 18, 19}};
+__device__ void fp_acc11(double* o, const double* a, const double* b, double s) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) o[FP_M11[i][j]] += s * (a[i] * b[j]);
+}
+__device__ void fp_acc21(double* o, const double* a, const double* b, double s) {
+    for (int i = 0; i < 10; ++i)
+        for (int j = 0; j < 4; ++j) o[FP_M21[i][j]] += s * (a[i] * b[j]);
+}
+__device__ double fp_horner(const double* c, int n, double z) {
+    double v = c[n];
+    for (int k = n - 1; k >= 0; --k) v = v * z + c[k];
+    return v;
+}
+__device__ void fp_zmul(const double* a, int na, const double* b, int nb, double* o) {
+    for (int k = 0; k <= na + nb; ++k) o[k] = 0.0;
+    for (int i = 0; i <= na; ++i)
+        for (int j = 0; j <= nb; ++j) o[i + j] += a[i] * b[j];
+}
+// the simple real roots of c[0] + ... + c[n] z^n inside the Cauchy bound, ascending: bisection between the roots of the
+// derivative, from the linear one upwards
+__device__ int fp_real_roots(const double* c, int n, double* roots) {
+    while (n > 0 && c[n] == 0.0) --n;
+    if (n < 1) return 0;
+    double bound = 0.0;
+    for (int k = 0; k < n; ++k) { const double r = fabs(c[k] / c[n]); if (r > bound) bound = r; }
+    bound += 1.0;
+    if (!(bound < 1e12)) bound = 1e12;
+    double d[11][11];
+    for (int i = 0; i <= n; ++i) d[0][i] = c[i];
+    for (int k = 1; k < n; ++k)
+        for (int i = 0; i <= n - k; ++i) d[k][i] = d[k - 1][i + 1] * (double)(i + 1);
+    double prev[10], cur[10];
+    int np = 0;
+    for (int k = n - 1; k >= 0; --k) {
+        const int deg = n - k;
+        int nc = 0;
+        for (int s = 0; s <= np; ++s) {
+            double lo = s == 0 ? -bound : prev[s - 1], hi = s == np ? bound : prev[s];
+            const double flo = fp_horner(d[k], deg, lo), fhi = fp_horner(d[k], deg, hi);
+            if (flo == 0.0) { if (s == 0) cur[nc++] = lo; continue; }
+            if (fhi == 0.0) { cur[nc++] = hi; continue; }
+            if ((flo < 0.0) == (fhi < 0.0)) continue;
+            for (int it = 0; it < 200; ++it) {
+                const double mid = 0.5 * (lo + hi);
+                if (!(mid > lo && mid < hi)) break;
+                const double fm = fp_horner(d[k], deg, mid);
+                if (fm == 0.0) { lo = hi = mid; break; }
+                if ((fm < 0.0) == (flo < 0.0)) lo = mid; else hi = mid;
+            }
+            cur[nc++] = 0.5 * (lo + hi);
+        }
+        np = nc;
+        for (int s = 0; s < nc; ++s) prev[s] = cur[s];
+    }
+    for (int s = 0; s < np; ++s) roots[s] = prev[s];
+    return np;
+}
+// 5 correspondences (K^-1-normalised) -> up to 10 matrices E, ascending in the root; returns their number
+__device__ int five_point(const double* x0, const double* y0, const double* x1, const double* y1, double* Es) {
+    double A[45], V[81];
+    for (int i = 0; i < 5; ++i) {
+        double* r = A + 9 * i;
+        r[0] = x1[i] * x0[i]; r[1] = x1[i] * y0[i]; r[2] = x1[i];
+        r[3] = y1[i] * x0[i]; r[4] = y1[i] * y0[i]; r[5] = y1[i];
+        r[6] = x0[i]; r[7] = y0[i]; r[8] = 1.0;
+    }
+    hestenes(A, 5, 9, V, 16);
+    double nn[9]; int null_col[4]; bool taken[9];
+    for (int j = 0; j < 9; ++j) { taken[j] = false; nn[j] = colnorm2(A, 5, 9, j); }
+    for (int t = 0; t < 4; ++t) {
+        int best = -1;
+        for (int j = 0; j < 9; ++j) if (!taken[j] && (best < 0 || nn[j] < nn[best])) best = j;
+        taken[best] = true;
+    }
+    for (int j = 0, t = 0; j < 9; ++j) if (taken[j]) null_col[t++] = j;
+    double E1[9][4];
+    for (int e = 0; e < 9; ++e)
+        for (int b = 0; b < 4; ++b) E1[e][b] = V[e * 9 + null_col[b]];
+    double EEt[9][10], tr[10], cons[10][20];
+    for (int e = 0; e < 9; ++e) for (int i = 0; i < 10; ++i) EEt[e][i] = 0.0;
+    for (int e = 0; e < 10; ++e) for (int i = 0; i < 20; ++i) cons[e][i] = 0.0;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < 3; ++k) fp_acc11(EEt[3 * r + c], E1[3 * r + k], E1[3 * c + k], 1.0);
+    for (int i = 0; i < 10; ++i) tr[i] = (EEt[0][i] + EEt[4][i]) + EEt[8][i];
+    {
+        double m0[10], m1[10], m2[10];
+        for (int i = 0; i < 10; ++i) { m0[i] = 0.0; m1[i] = 0.0; m2[i] = 0.0; }
+        fp_acc11(m0, E1[4], E1[8], 1.0); fp_acc11(m0, E1[5], E1[7], -1.0);
+        fp_acc11(m1, E1[3], E1[8], 1.0); fp_acc11(m1, E1[5], E1[6], -1.0);
+        fp_acc11(m2, E1[3], E1[7], 1.0); fp_acc11(m2, E1[4], E1[6], -1.0);
+        fp_acc21(cons[0], m0, E1[0], 1.0); fp_acc21(cons[0], m1, E1[1], -1.0); fp_acc21(cons[0], m2, E1[2], 1.0);
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double* o = cons[1 + 3 * r + c];
+            for (int k = 0; k < 3; ++k) fp_acc21(o, EEt[3 * r + k], E1[3 * k + c], 2.0);
+            fp_acc21(o, tr, E1[3 * r + c], -1.0);
+        }
+    for (int col = 0; col < 10; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 10; ++r) if (fabs(cons[r][col]) > fabs(cons[piv][col])) piv = r;
+        const double p = cons[piv][col];
+        if (!(fabs(p) > 0.0) || !(fabs(p) < INFINITY)) return 0;
+        if (piv != col)
+            for (int k = 0; k < 20; ++k) { const double t = cons[piv][k]; cons[piv][k] = cons[col][k]; cons[col][k] = t; }
+        for (int k = 0; k < 20; ++k) cons[col][k] = cons[col][k] / p;
+        for (int r = 0; r < 10; ++r) {
+            if (r == col) continue;
+            const double f = cons[r][col];
+            if (f == 0.0) continue;
+            for (int k = 0; k < 20; ++k) cons[r][k] = cons[r][k] - f * cons[col][k];
+        }
+    }
+    double B[3][3][5];
+    for (int q = 0; q < 3; ++q) {
+        const double* e = cons[4 + 2 * q] + 10; const double* f = cons[5 + 2 * q] + 10;
+        for (int part = 0; part < 2; ++part) {
+            const double* pe = e + 3 * part; const double* pf = f + 3 * part;
+            B[q][part][0] = pe[2]; B[q][part][1] = pe[1] - pf[2]; B[q][part][2] = pe[0] - pf[1]; B[q][part][3] = -pf[0]; B[q][part][4] = 0.0;
+        }
+        B[q][2][0] = e[9]; B[q][2][1] = e[8] - f[9]; B[q][2][2] = e[7] - f[8]; B[q][2][3] = e[6] - f[7]; B[q][2][4] = -f[6];
+    }
+    double t1[8], t2[8], c0[8], c1[8], c2[7], d0[11], d1[11], d2[11], det[11];
+    fp_zmul(B[1][1], 3, B[2][2], 4, t1); fp_zmul(B[1][2], 4, B[2][1], 3, t2);
+    for (int k = 0; k < 8; ++k) c0[k] = t1[k] - t2[k];
+    fp_zmul(B[1][0], 3, B[2][2], 4, t1); fp_zmul(B[1][2], 4, B[2][0], 3, t2);
+    for (int k = 0; k < 8; ++k) c1[k] = t1[k] - t2[k];
+    fp_zmul(B[1][0], 3, B[2][1], 3, t1); fp_zmul(B[1][1], 3, B[2][0], 3, t2);
+    for (int k = 0; k < 7; ++k) c2[k] = t1[k] - t2[k];
+    fp_zmul(B[0][0], 3, c0, 7, d0); fp_zmul(B[0][1], 3, c1, 7, d1); fp_zmul(B[0][2], 4, c2, 6, d2);
+    for (int k = 0; k < 11; ++k) det[k] = (d0[k] - d1[k]) + d2[k];
+    for (int k = 0; k < 11; ++k) if (!(fabs(det[k]) < INFINITY)) return 0;
+    double roots[10];
+    const int nr = fp_real_roots(det, 10, roots);
+    int n = 0;
+    for (int s = 0; s < nr; ++s) {
+        const double z = roots[s];
+        double bx[3], by[3], b1[3];
+        for (int q = 0; q < 3; ++q) { bx[q] = fp_horner(B[q][0], 3, z); by[q] = fp_horner(B[q][1], 3, z); b1[q] = fp_horner(B[q][2], 4, z); }
+        int pa = 0, pb = 1;
+        double den = bx[0] * by[1] - by[0] * bx[1];
+        {
+            const double d02 = bx[0] * by[2] - by[0] * bx[2], d12 = bx[1] * by[2] - by[1] * bx[2];
+            if (fabs(d02) > fabs(den)) { den = d02; pa = 0; pb = 2; }
+            if (fabs(d12) > fabs(den)) { den = d12; pa = 1; pb = 2; }
+        }
+        const double x = (by[pa] * b1[pb] - b1[pa] * by[pb]) / den, y = (b1[pa] * bx[pb] - bx[pa] * b1[pb]) / den;
+        double E0[9];
+        bool finite = true;
+        for (int e = 0; e < 9; ++e) {
+            E0[e] = ((x * E1[e][0] + y * E1[e][1]) + z * E1[e][2]) + E1[e][3];
+            if (!(fabs(E0[e]) < INFINITY)) finite = false;
+        }
+        if (!finite) continue;
+        if (essential_project(E0, Es + 9 * n)) ++n;
+    }
+    return n;
+}
+// one thread per sample; its (up to) ten solutions are rows 10 h .. 10 h + 9 of the table (unused rows: E = 0)
+__global__ __launch_bounds__(64) void k_e5_hyp(EHypArgs a) {
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.H) return;
+    int32_t id[5];
+    bool ok = true;
+    if (a.sample_idx) {
+        for (int k = 0; k < 5; ++k) { id[k] = a.sample_idx[5 * h + k]; if (id[k] < 0 || id[k] >= a.M) ok = false; }
+    } else philox_sample5(a.seed, (uint32_t)h, (uint32_t)a.M, id);
+    double Es[90];
+    int n = 0;
+    if (ok) {
+        const double fx = a.K[0], sk = a.K[1], cx = a.K[2], fy = a.K[4], cy = a.K[5];
+        double x0[5], y0[5], x1[5], y1[5];
+        for (int k = 0; k < 5; ++k) {
+            const long i = id[k];
+            const double u0 = a.p0[i * a.sp.xi], v0 = a.p0[i * a.sp.xi + a.sp.xc];
+            const double u1 = a.p1[i * a.sp.xi], v1 = a.p1[i * a.sp.xi + a.sp.xc];
+            y0[k] = (v0 - cy) / fy; x0[k] = ((u0 - cx) - sk * y0[k]) / fx;
+            y1[k] = (v1 - cy) / fy; x1[k] = ((u1 - cx) - sk * y1[k]) / fx;
+        }
+        n = five_point(x0, y0, x1, y1, Es);
+    }
+    for (int s = 0; s < 10; ++s) {
+        double* o = a.E48 + 48 * (10 * (long)h + s);
+        for (int k = 0; k < 9; ++k) o[k] = s < n ? Es[9 * s + k] : 0.0;
+        for (int k = 9; k < 48; ++k) o[k] = 0.0;
+    }
+}
+
 struct EScoreArgs {
     const double *p0, *p1; vo_strides sp; int M; const double* K; int H; double thr; const double* E; int e_stride;
     int32_t* cnt; unsigned long long* cost; // H x 4: solution 0 carries the hypothesis, 1..3 are disabled
@@ -1226,15 +1440,20 @@ __global__ __launch_bounds__(256) void k_e_inliers(EInlArgs a) {
 // d_E_in (optional): H x 9 hypotheses to score instead of sampling ("identical hypotheses").
 int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_strides sp, int M, const double* d_K,
                         const vo_ransac_opts* o, const int32_t* d_sample_idx, const double* d_E_in, vo_ransac_work* w,
-                        void* d_out, uint8_t* d_inliers) {
-    const int H = o->num_hyp;
-    if (H < 1 || M < 8 || !(o->max_reproj_err > 0)) { ctx->last_error = "essential: need num_hyp >= 1, M >= 8, MaxDistance > 0"; return VO_ERR_BAD_ARG; }
+                        void* d_out, uint8_t* d_inliers, int solver) {
+    // solver 8: one matrix per sample (eight-point); 5: Nister's five-point solver, ten rows of the table per sample
+    // (w is prepared for 10 x num_hyp rows)
+    if (solver != 8 && solver != 5) { ctx->last_error = "essential: solver must be 8 or 5"; return VO_ERR_BAD_ARG; }
+    const int rpt = (solver == 5 && !d_E_in) ? 10 : 1;
+    const int H = o->num_hyp * rpt;
+    if (o->num_hyp < 1 || M < solver || !(o->max_reproj_err > 0)) { ctx->last_error = "essential: need num_hyp >= 1, M >= the sample size, MaxDistance > 0"; return VO_ERR_BAD_ARG; }
     const double* E = w->Rt; int e_stride = 48;
     if (d_E_in) { E = d_E_in; e_stride = 9; }
     else {
         EHypArgs h;
-        h.p0 = d_p0; h.p1 = d_p1; h.sp = sp; h.M = M; h.K = d_K; h.H = H; h.seed = o->seed; h.sample_idx = d_sample_idx; h.E48 = w->Rt;
-        hipLaunchKernelGGL(k_e_hyp, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, h);
+        h.p0 = d_p0; h.p1 = d_p1; h.sp = sp; h.M = M; h.K = d_K; h.H = o->num_hyp; h.seed = o->seed; h.sample_idx = d_sample_idx; h.E48 = w->Rt;
+        if (solver == 5) hipLaunchKernelGGL(k_e5_hyp, dim3((o->num_hyp + 63) / 64), dim3(64), 0, ctx->stream, h);
+        else hipLaunchKernelGGL(k_e_hyp, dim3((H + 63) / 64), dim3(64), 0, ctx->stream, h);
     }
     EScoreArgs s;
     s.p0 = d_p0; s.p1 = d_p1; s.sp = sp; s.M = M; s.K = d_K; s.H = H; s.thr = o->max_reproj_err; s.E = E; s.e_stride = e_stride;
@@ -1248,7 +1467,8 @@ int vo_launch_essential(vo_ctx* ctx, const double* d_p0, const double* d_p1, vo_
     BestArgs b;
     b.bound_out = nullptr; b.sieve_out = nullptr; b.qthr = 0;
     b.cnt = w->cnt; b.cost = w->cost; b.Rt = w->Rt; b.H = H; b.M = M; b.mode = 1; b.min_inl = o->min_inliers;
-    b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = 8; b.later_stage = 0; b.M_dev = nullptr;
+    b.confidence = o->confidence; b.out = (double*)d_out; b.sample_size = solver; b.later_stage = 0; b.M_dev = nullptr;
+    b.rows_per_trial = rpt;
     hipLaunchKernelGGL(k_best<256>, dim3(1), dim3(256), 0, ctx->stream, b);
     EInlArgs in;
     in.p0 = d_p0; in.p1 = d_p1; in.sp = sp; in.M = M; in.K = d_K; in.thr = o->max_reproj_err; in.out = (double*)d_out; in.inliers = d_inliers;

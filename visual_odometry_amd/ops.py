@@ -253,6 +253,36 @@ def essential_ransac(pts0, pts1, K, num_hyp=2000, max_distance=0.09, confidence=
     return out
 
 
+def essential_ransac_five(pts0, pts1, K, num_hyp=2000, max_distance=0.09, confidence=0.995, seed=1023, min_inliers=5,
+                          sample_idx=None, col_major=False, want_all=False, ctx=None):
+    """The relative-pose step of the bootstrap (modules/bootstrap.m:76-79) around Nister's five-point solver -- works on
+    planar scenes, which the eight-point algorithm does not -> dict(E, inliers, status, best_hyp, trials,
+    num_inliers[, counts, costs, Es]); the per-hypothesis outputs have ten slots per sample, best_hyp is a slot index."""
+    ctx = ctx or Context.default()
+    cm = 1 if col_major else 0
+    p0 = _mat(pts0, cm, np.float64, 2) if np.size(pts0) else np.zeros((0, 2))
+    p1 = _mat(pts1, cm, np.float64, 2) if np.size(pts1) else np.zeros((0, 2))
+    M = p0.shape[0]
+    if p1.shape[0] != M:
+        raise ValueError("point sets differ in length")
+    H = int(num_hyp)
+    o = RansacOpts(H, float(max_distance), float(confidence), int(seed), 1, int(min_inliers))
+    si = None if sample_idx is None else np.ascontiguousarray(sample_idx, np.int32).reshape(H, 5)
+    E = np.zeros((3, 3), order="F" if cm else "C"); inl = np.zeros(max(M, 1), np.uint8)
+    info = RansacInfo()
+    cnt = np.zeros(10 * H, np.int32) if want_all else None
+    cost = np.zeros(10 * H, np.uint64) if want_all else None
+    Es = np.zeros((10 * H, 3, 3)) if want_all else None
+    Kc = _K(K)
+    ctx.call("vo_essential_ransac_five", Layout(cm, 1), ptr(p0), ptr(p1), M, ptr(Kc), C.byref(o), ptr(si), ptr(E),
+             ptr(inl), C.byref(info), ptr(cnt), ptr(cost), ptr(Es))
+    out = dict(E=np.ascontiguousarray(E), inliers=inl[:M].astype(bool), status=info.status, best_hyp=info.best_hyp,
+               trials=info.trials_used, num_inliers=info.num_inliers)
+    if want_all:
+        out.update(counts=cnt, costs=cost, Es=Es)
+    return out
+
+
 def p3p_batch(world_pts, bearings, ctx=None):
     """old/p3p.m:41-217 batched: n x 3 x 3 points / unit bearings -> n x 4 x 12 [C(3) R(9)]."""
     ctx = ctx or Context.default()
