@@ -1,7 +1,8 @@
 """CPU restatement of modules/bootstrap.m:24-135 on top of the C oracle.  TEST INFRASTRUCTURE ONLY
 (oracle/vo_oracle.h); PARITY UNPINNED: estimateEssentialMatrix / relativeCameraPose /
-triangulateMultiview are closed toolbox functions, defined here (N10, essential.c) as MSAC around the
-normalised eight-point algorithm, the textbook four-fold decomposition with a cheirality vote, and the
+triangulateMultiview are closed toolbox functions, defined here as MSAC around Nister's five-point solver (N10b,
+five_point.c; Solver='eight-point': the normalised eight-point algorithm, N10, essential.c), the textbook four-fold
+decomposition with a cheirality vote, and the
 two-view DLT of the frame step.  Zero-based (u, v) coordinates, K in the same origin."""
 import numpy as np
 
@@ -10,7 +11,7 @@ from . import oracle
 DEFAULTS = dict(MinDepth=0.0, MaxDepth=5000.0, MinNumLandmarks=50, MinQuality=0.01, FilterSize=5,   # :13-21
                 uniformFeaturesPercentage=100.0, MaxNumTrials=2000, Confidence=99.5, MaxDistance=0.09,  # :76-79
                 levels=4, max_bidir=2.0, block=41, max_iters=50,                                     # KLTTracker() defaults
-                seed=1023, max_attempts=20, threads=4)
+                seed=1023, max_attempts=20, threads=4, Solver="five-point")
 
 
 def decompose_essential(E):
@@ -58,9 +59,9 @@ def bootstrap(img0, img1, K, **kw):
     m1 = np.stack([qu, qv], 1)[valid]
     pose0 = np.vstack([np.eye(3), np.zeros((1, 3))])
     for attempt in range(o["max_attempts"]):                                                          # :74
-        r = oracle.essential_ransac(m0, m1, K, num_hyp=o["MaxNumTrials"], max_distance=o["MaxDistance"],
-                                    confidence=o["Confidence"] / 100.0, seed=o["seed"] + attempt, min_inliers=8,
-                                    threads=o["threads"])                                            # :76-79
+        solve = oracle.essential_ransac5 if o["Solver"] == "five-point" else oracle.essential_ransac
+        r = solve(m0, m1, K, num_hyp=o["MaxNumTrials"], max_distance=o["MaxDistance"], confidence=o["Confidence"] / 100.0,
+                  seed=o["seed"] + attempt, min_inliers=5 if o["Solver"] == "five-point" else 8, threads=o["threads"])  # :76-79
         inl = r["inliers"]
         if r["status"] != 0 or inl.sum() < o["MinNumLandmarks"]:                                      # :83-86
             continue

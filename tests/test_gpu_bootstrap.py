@@ -165,3 +165,16 @@ def test_five_point_statuses(ctx):
     r = ops.essential_ransac_five(p0, junk, synth.KITTI_K, num_hyp=50, min_inliers=30)
     o = oracle.essential_ransac5(p0, junk, synth.KITTI_K, num_hyp=50, min_inliers=30)
     assert r["status"] == o["status"] == 2
+
+
+@pytest.mark.parametrize("solver", ["five-point", "eight-point"])
+def test_bootstrap_by_either_solver_matches_the_oracle(ctx, solver):
+    frames, poses, lift = synth.relief_sequence(4, K)
+    kp_o, X_o, rep_o, pose_o, info_o = obootstrap.bootstrap(frames[0], frames[2], K, threads=8, Solver=solver)
+    K1 = K.copy(); K1[0, 2] += 1; K1[1, 2] += 1
+    kp, X, rep, pose, info = modules.bootstrap(frames[0], frames[2], modules.CameraParams(K1), return_info=True, Solver=solver)
+    assert (info["inliers"], info["attempts"], info["trials"]) == (info_o["inliers"], info_o["attempts"], info_o["trials"])
+    assert len(kp) == len(kp_o) > 500 and np.abs(kp - 1 - kp_o).max() < 0.01
+    np.testing.assert_allclose(pose, pose_o, rtol=1e-4, atol=1e-5)
+    Ct = poses[2][3]
+    assert np.abs(pose[:3] - poses[2][:3]).max() < 0.02 and np.abs(pose[3] - Ct / np.linalg.norm(Ct)).max() < 0.15

@@ -305,13 +305,24 @@ class VisualOdometry:
 
 
 # ---------------------------------------------------------------- bootstrap (modules/bootstrap.m)
+def _essential(m0, m1, K, solver, **kw):
+    """the relative-pose step by either solver: 'five-point' (Nister; what the toolbox function is built around, works on
+    planar scenes; definition N10b) or 'eight-point' (definition N10)"""
+    if solver == "five-point":
+        return ops.essential_ransac_five(m0, m1, K, min_inliers=5, **kw)
+    if solver == "eight-point":
+        return ops.essential_ransac(m0, m1, K, min_inliers=8, **kw)
+    raise ValueError("Solver must be 'five-point' or 'eight-point'")
+
+
 def estimateEssentialMatrix(matchedPoints1, matchedPoints2, cameraParams, MaxNumTrials=500, Confidence=99,
-                            MaxDistance=0.1, Seed=1023):
-    """[E, inliersIndex, status] of the toolbox call at modules/bootstrap.m:76-79: MSAC around the
-    normalised eight-point algorithm (definition N10).  E satisfies x2' E x1 = 0 on normalised points."""
+                            MaxDistance=0.1, Seed=1023, Solver="five-point"):
+    """[E, inliersIndex, status] of the toolbox call at modules/bootstrap.m:76-79: MSAC around a five-point solver
+    (definition N10b; Solver='eight-point': the normalised eight-point algorithm, N10).  E satisfies x2' E x1 = 0 on
+    normalised points."""
     K = cameraParams.K if hasattr(cameraParams, "K") else np.asarray(cameraParams.IntrinsicMatrix).T
-    r = ops.essential_ransac(matchedPoints1, matchedPoints2, K, num_hyp=MaxNumTrials, max_distance=MaxDistance,
-                             confidence=Confidence / 100.0, seed=Seed, min_inliers=8)
+    r = _essential(matchedPoints1, matchedPoints2, K, Solver, num_hyp=MaxNumTrials, max_distance=MaxDistance,
+                   confidence=Confidence / 100.0, seed=Seed)
     return r["E"], r["inliers"], r["status"]
 
 
@@ -345,11 +356,12 @@ def relativeCameraPose(E, cameraParams, inlierPoints1, inlierPoints2):
 
 def bootstrap(img0, img1, cameraParams, PlotResult=False, MinDepth=0.0, MaxDepth=5000.0, MinNumLandmarks=50,
               FeatureMatchingMode="KLT", MinQuality=0.01, FilterSize=5, uniformFeaturesPercentage=100.0,
-              Seed=1023, MaxAttempts=20, return_info=False):
+              Seed=1023, MaxAttempts=20, return_info=False, Solver="five-point"):
     """[keypoints, landmarks, reproError, pose] = bootstrap(img0, img1, cameraParams, ...)
     (modules/bootstrap.m:1-135).  'HardMatching' (:40-55, descriptor matching) is not built: only the
     default KLT mode.  The reference loops until enough landmarks exist (:74); here at most MaxAttempts
-    reseeded attempts, then an error."""
+    reseeded attempts, then an error.  Solver: the minimal solver inside estimateEssentialMatrix (:76-79), 'five-point'
+    (default) or 'eight-point'."""
     del PlotResult
     if FeatureMatchingMode != "KLT":
         raise NotImplementedError("bootstrap: only FeatureMatchingMode='KLT' is built")
@@ -365,8 +377,7 @@ def bootstrap(img0, img1, cameraParams, PlotResult=False, MinDepth=0.0, MaxDepth
     m0 = pts0.astype(np.float64)[validity]; m1 = points[validity]                                                        # :59-60
     pose0 = np.vstack([np.eye(3), np.zeros((1, 3))])
     for attempt in range(int(MaxAttempts)):                                                                               # :74
-        r = ops.essential_ransac(m0, m1, K, num_hyp=2000, max_distance=0.09, confidence=0.995, seed=Seed + attempt,
-                                 min_inliers=8)                                                                          # :76-79
+        r = _essential(m0, m1, K, Solver, num_hyp=2000, max_distance=0.09, confidence=0.995, seed=Seed + attempt)       # :76-79
         inl = r["inliers"]
         if r["status"] != 0 or inl.sum() < MinNumLandmarks:                                                               # :83-86
             continue
