@@ -359,8 +359,9 @@ typedef struct vo_frame_info {
  * the np promotable candidates in candidate order; cap = maxNumLandmarks.  d_accepted[e] (meaningful for e >= n0): the
  * candidate is taken into the landmarks at its turn (:116-127: below the cap it is appended, at the cap it replaces the
  * FIRST maximum, taken before the edit, if its own error is not larger); d_survives[e]: the entry is a landmark when the
- * loop has ended.  What vo_frame_submit runs for pools beyond a few hundred entries, O(n log n): one stable merge sort
- * by error gives both (csrc/vo_frame.hip).  Device arrays, asynchronous launches, one synchronisation at the end. */
+ * loop has ended.  What vo_frame_submit runs for pools beyond a few hundred entries, O(n log n): runs of the pool sorted
+ * stably by error, in which every entry then looks itself up, give both (csrc/vo_frame.hip).  Device arrays,
+ * asynchronous launches, one synchronisation at the end. */
 int vo_dev_merge_ranks(vo_ctx* ctx, const double* d_values, int n0, int np, int cap, uint8_t* d_survives, uint8_t* d_accepted);
 int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* opts, int nu, int nv, const double K[9], vo_frame_state** out);
 int vo_frame_destroy(vo_ctx* ctx, vo_frame_state* st);
