@@ -796,11 +796,13 @@ __global__ __launch_bounds__(64) void k_p3p_batch(const double* P, const double*
 } // namespace
 
 static int score_chunks(int nblocks, int npoints) {
-    // one-wave blocks: split the points over blockIdx.y until the launch has about 4 waves per SIMD (a piece no
+    // one-wave blocks: split the points over blockIdx.y until the launch has about a wave per SIMD (1024 blocks; 3072
+    // -- 4 waves per SIMD, the first choice -- is 0.01 ms faster for the chain alone and 0.005-0.01 ms slower for the
+    // step and the frame loop at the stress size, where the launch competes with tracking waves for slots; a piece no
     // shorter than 128 points; pieces of at least 1024 points until round 3: the frame loop at 2k landmarks runs its
     // 64-hypothesis prefix over 2000 points, a launch of 16 waves each walking all of them -- 0.240 -> 0.222 ms per
     // frame with the short pieces, no difference at 25k points.  Counts and costs are integer sums: the same bits)
-    static const int target = [] { const char* e = getenv("VO_SCORE_BLOCKS"); return e ? atoi(e) : 3072; }();   // A/B switch
+    static const int target = [] { const char* e = getenv("VO_SCORE_BLOCKS"); return e ? atoi(e) : 1024; }();   // A/B switch
     static const int piece = [] { const char* e = getenv("VO_SCORE_PIECE"); return e ? atoi(e) : 128; }();      // A/B switch
     int c = 1;
     while (c < 64 && nblocks * c < target && npoints / (2 * c) >= piece) c *= 2;
