@@ -12,6 +12,7 @@
  *   vo_select_keypoints_greedy
  *   vo_triangulate_candidates <- per-candidate loop body         modules/VisualOdometry.m:87-113,
  *                                                                modules/candidateTriangulation.m:37-57
+ *   vo_triangulate_points   <- the toolbox call `triangulate`    modules/VisualOdometry.m:97-101 (one candidate a call)
  *   vo_angle_deg            <- calculateAngleDeg                 utils/calculateAngleDeg.m:1-11
  *   vo_in_front             <- isInFrontOfCamera                 modules/isInFrontOfCamera.m:1-12
  *   vo_p3p_ransac           <- estimateWorldCameraPose call      modules/VisualOdometry.m:285-289,
@@ -191,6 +192,17 @@ int vo_triangulate_candidates(vo_ctx* ctx, vo_layout lay, const double* first_xy
                               const double* first_poses, int P, const int32_t* first_pose_idx, int C,
                               const double* curr_pose, const double* K, double* out_X,
                               double* out_reproj, double* out_angle_deg, uint8_t* out_valid);
+
+/* `[worldPoints, reprojectionErrors, validIndex] = triangulate(matchedPoints1, matchedPoints2, camMatrix1, camMatrix2)`
+ * with the argument shapes of the reference's call sites (modules/VisualOdometry.m:97-101,
+ * modules/candidateTriangulation.m:47-51, processFrame.m:55-59): n point pairs (n x 2 each), two 4 x 3 camera matrices
+ * ([X 1] * camMat = [u v w] * w, as `cameraMatrix` returns them), X n x 3, error = mean over the two views, valid =
+ * positive depth in both.  What matlab/triangulate.m binds, so that the UNMODIFIED class method
+ * (modules/VisualOdometry.m:87-142) reaches the GPU -- one candidate a call; the batched form is
+ * vo_triangulate_candidates. */
+int vo_triangulate_points(vo_ctx* ctx, vo_layout lay, const double* pts0, const double* pts1, int n,
+                          const double* cam_mat0, const double* cam_mat1, double* out_X, double* out_reproj,
+                          uint8_t* out_valid);
 
 /* utils/calculateAngleDeg.m:1-11, batched over n landmarks (n x 3) */
 int vo_angle_deg(vo_ctx* ctx, vo_layout lay, const double* landmarks, int n, const double* pose0,

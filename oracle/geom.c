@@ -134,6 +134,33 @@ void vo_or_triangulate(const double* xy0, const double* xy1, const double* poses
     }
 }
 
+/* the toolbox call itself, `triangulate(matchedPoints1, matchedPoints2, camMatrix1, camMatrix2)` as the reference makes
+ * it (modules/VisualOdometry.m:97-101, modules/candidateTriangulation.m:47-51, processFrame.m:55-59): the same DLT,
+ * error and validity as above with the two 4x3 camera matrices given (row-major), no angle. */
+void vo_or_triangulate_cam(const double* xy0, const double* xy1, const double* cam0, const double* cam1, int n,
+                           double* X, double* reproj, uint8_t* valid) {
+    for (int i = 0; i < n; ++i) {
+        double A[16], h[4];
+        const double x0 = xy0[2 * i], y0 = xy0[2 * i + 1], x1 = xy1[2 * i], y1 = xy1[2 * i + 1];
+        for (int k = 0; k < 4; ++k) {
+            A[0 * 4 + k] = x0 * cam0[k * 3 + 2] - cam0[k * 3 + 0];
+            A[1 * 4 + k] = y0 * cam0[k * 3 + 2] - cam0[k * 3 + 1];
+            A[2 * 4 + k] = x1 * cam1[k * 3 + 2] - cam1[k * 3 + 0];
+            A[3 * 4 + k] = y1 * cam1[k * 3 + 2] - cam1[k * 3 + 1];
+        }
+        svd4_last(A, h);
+        double Xi[3] = {h[0] / h[3], h[1] / h[3], h[2] / h[3]};
+        double u, v, w0, w1, e0, e1;
+        project(cam0, Xi, &u, &v, &w0);
+        e0 = sqrt((u - x0) * (u - x0) + (v - y0) * (v - y0));
+        project(cam1, Xi, &u, &v, &w1);
+        e1 = sqrt((u - x1) * (u - x1) + (v - y1) * (v - y1));
+        X[3 * i] = Xi[0]; X[3 * i + 1] = Xi[1]; X[3 * i + 2] = Xi[2];
+        reproj[i] = 0.5 * (e0 + e1);
+        valid[i] = (uint8_t)(w0 > 0.0 && w1 > 0.0);
+    }
+}
+
 /* modules/VisualOdometry.m:48-61 */
 void vo_or_reproj_error(const double* xy, const double* X, int n, const double* pose, const double* K, double* err) {
     double cam[12];

@@ -201,6 +201,16 @@ def triangulate(xy0, xy1, poses0, pose1, K):
     return X, rep, ang, val.astype(bool)
 
 
+def triangulate_cam(xy0, xy1, cam0, cam1):
+    """the toolbox call `triangulate(p1, p2, camMatrix1, camMatrix2)` (modules/VisualOdometry.m:97-101): 4x3 matrices given"""
+    xy0 = _c(xy0, np.float64).reshape(-1, 2); xy1 = _c(xy1, np.float64).reshape(-1, 2)
+    n = xy0.shape[0]
+    cam0 = _c(cam0, np.float64).reshape(4, 3); cam1 = _c(cam1, np.float64).reshape(4, 3)
+    X = np.zeros((n, 3)); rep = np.zeros(n); val = np.zeros(n, np.uint8)
+    lib().vo_or_triangulate_cam(_p(xy0), _p(xy1), _p(cam0), _p(cam1), n, _p(X), _p(rep), _p(val))
+    return X, rep, val.astype(bool)
+
+
 def reproj_error(xy, X, pose43, K):
     xy = _c(xy, np.float64).reshape(-1, 2); X = _c(X, np.float64).reshape(-1, 3)
     pose43 = _c(pose43, np.float64); K = _c(K, np.float64)

@@ -136,6 +136,8 @@ void vo_or_in_front(const double* cam43, const double* X, int n, uint8_t* valid)
 void vo_or_triangulate(const double* xy0, const double* xy1, const double* poses0 /* n x 12 */,
                        const double* pose1, const double* K, int n, double* X, double* reproj,
                        double* angle_deg, uint8_t* valid);
+void vo_or_triangulate_cam(const double* xy0, const double* xy1, const double* cam0 /* 4x3 row-major */, const double* cam1,
+                           int n, double* X, double* reproj, uint8_t* valid);
 void vo_or_reproj_error(const double* xy, const double* X, int n, const double* pose43,
                         const double* K, double* err);
 

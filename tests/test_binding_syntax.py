@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
 def test_mex_gateways_are_well_formed_cxx():
     srcs = sorted(glob.glob(os.path.join(ROOT, "mex", "*.cpp")))
-    assert len(srcs) >= 7, srcs
+    assert len(srcs) >= 8, srcs
     for src in srcs:
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-unused-function",
                             "-I" + os.path.join(ROOT, "tests", "stubs"), "-I" + os.path.join(ROOT, "include"), src],
@@ -81,6 +81,30 @@ def test_matlab_shadows_keep_the_reference_signatures(shadow, func, ref, line, o
             assert re.search(r"function.*\b%s\s*\(" % func, f.readlines()[line - 1]), f"{ref}:{line} is not the signature line"
         assert len(ro) == len(o) and len(ri) == len(i)
         assert ri[:len(ins)][1 if func == "track" else 0:] == ins[1 if func == "track" else 0:] and (func == "KLTTracker" or ro == outs)
+
+
+def test_toolbox_shadows_take_what_the_reference_passes():
+    """triangulate and estimateWorldCameraPose are toolbox names: the reference holds no signature line for them, only
+    call sites (modules/VisualOdometry.m:97-101 and :285-289).  The shadows take as many positional arguments and
+    return as many outputs as those calls use."""
+    o, i = _signature(os.path.join(ROOT, "matlab", "triangulate.m"), "triangulate")
+    assert len(o) == 3 and len(i) == 4, (o, i)
+    o, i = _signature(os.path.join(ROOT, "matlab", "estimateWorldCameraPose.m"), "estimateWorldCameraPose")
+    assert len(o) == 4 and len(i) == 4, (o, i)          # three positional arguments + the name-value struct
+    ref_path = "/root/reference/modules/VisualOdometry.m"
+    if os.path.exists(ref_path):
+        text = re.sub(r"\.\.\.[^\n]*\n", " ", open(ref_path).read())
+        m = re.search(r"\[([^\]]*)\]\s*=\s*triangulate\(([^;]*)\);", text)
+        assert m and len(m.group(1).split(",")) == 3
+        args = [a for a in (x.strip() for x in m.group(2).split(",")) if a]
+        # (i,:) index expressions hold commas of their own: count top-level arguments
+        depth = 0; n = 1
+        for ch in m.group(2):
+            depth += ch == "("; depth -= ch == ")"
+            n += ch == "," and depth == 0
+        assert n - (1 if m.group(2).strip().startswith(",") else 0) == 4, m.group(2)
+        m = re.search(r"\[([^\]]*)\]\s*=\s*estimateWorldCameraPose\(", text)
+        assert m and len(m.group(1).split(",")) == 4
 
 
 def test_name_value_options_of_the_shadows_are_the_references():

@@ -318,6 +318,38 @@ def test_triangulation_pose_table_and_scale(ctx):
     np.testing.assert_array_equal(bad[3][:2], ok2)                 # the good ones beside them are what the oracle says
 
 
+def test_triangulate_with_camera_matrices(ctx):
+    """vo_triangulate_points -- the toolbox call `triangulate(p1, p2, camMatrix1, camMatrix2)` as the unmodified class
+    method makes it (modules/VisualOdometry.m:97-101), one candidate a call, and batched -- against the oracle, and
+    against the batched candidate entry point, which must agree bit for bit (same DLT on the same matrices)."""
+    xy0, xy1, poses0, pose1, Xt = synth.triangulation_scene(3000)
+    cam1 = oracle.camera_matrix(pose1, K)
+    Xc, repc, angc, validc = ops.triangulate_candidates(xy0, xy1, poses0.reshape(-1, 4, 3), pose1, K)
+    for i in (0, 1, 17, 2999):                            # one candidate a call
+        cam0 = oracle.camera_matrix(poses0[i], K)
+        for cm in (False, True):
+            X, rep, valid = ops.triangulate(xy0[i], xy1[i], cam0, cam1, col_major=cm)
+            Xo, repo, valido = oracle.triangulate_cam(xy0[i], xy1[i], cam0, cam1)
+            assert valid[0] == valido[0]
+            np.testing.assert_allclose(X, Xo, rtol=1e-12); np.testing.assert_allclose(rep, repo, rtol=1e-9, atol=1e-12)
+            # the device builds the camera matrix of the batched entry point with the oracle's expression
+            assert X.tobytes() == np.ascontiguousarray(Xc[i:i + 1]).tobytes() and rep[0] == repc[i] and valid[0] == validc[i]
+    sel = np.flatnonzero((poses0.reshape(len(poses0), -1) == poses0.reshape(len(poses0), -1)[0]).all(1))   # one first pose
+    assert len(sel) > 100
+    cam0 = oracle.camera_matrix(poses0[sel[0]], K)
+    for cm in (False, True):
+        X, rep, valid = ops.triangulate(xy0[sel], xy1[sel], cam0, cam1, col_major=cm)
+        Xo, repo, valido = oracle.triangulate_cam(xy0[sel], xy1[sel], cam0, cam1)
+        np.testing.assert_array_equal(valid, valido)
+        np.testing.assert_allclose(X, Xo, rtol=1e-12); np.testing.assert_allclose(rep, repo, rtol=1e-9, atol=1e-12)
+    Xs, reps, vals = modules.triangulate(xy0[sel].astype(np.float32), xy1[sel].astype(np.float32), cam0, cam1)
+    assert Xs.dtype == np.float32 and reps.dtype == np.float32 and vals.dtype == bool      # class follows the points
+    e = ops.triangulate(np.zeros((0, 2)), np.zeros((0, 2)), cam0, cam1)
+    assert e[0].shape == (0, 3) and e[1].shape == (0,) and e[2].shape == (0,)
+    with pytest.raises(ValueError):
+        ops.triangulate(xy0[:3], xy1[:2], cam0, cam1)
+
+
 def test_angle_cheirality_reprojection(ctx):
     rng = np.random.default_rng(9)
     X = rng.normal(size=(1000, 3)) * 10

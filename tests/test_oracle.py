@@ -206,6 +206,22 @@ def test_triangulation_flags_points_behind_a_camera():
     assert not valid[0] and np.allclose(Xe[0], X[0], atol=1e-8)
 
 
+def test_triangulation_from_camera_matrices_is_the_same_triangulation():
+    """the toolbox call's shape (modules/VisualOdometry.m:97-101): two 4 x 3 camera matrices instead of poses and K"""
+    xy0, xy1, poses0, pose1, X = synth.triangulation_scene(64, noise=0.3)
+    cam1 = oracle.camera_matrix(pose1, K)
+    Xe, rep, ang, valid = oracle.triangulate(xy0, xy1, poses0, pose1, K)
+    for i in range(len(xy0)):                            # one candidate a call, as the class method's loop makes it
+        Xi, ri, vi = oracle.triangulate_cam(xy0[i], xy1[i], oracle.camera_matrix(poses0[i], K), cam1)
+        assert Xi.tobytes() == Xe[i:i + 1].tobytes() and ri[0] == rep[i] and vi[0] == valid[i]
+    # n pairs under one pair of matrices, noise free: the points come back
+    pose0 = synth.pose43(synth.rot_y(2.0), [0.0, 0.0, 0.0]); pose2 = synth.pose43(synth.rot_y(-1.0), [1.5, 0.1, 0.2])
+    Xt = np.random.default_rng(3).uniform([-10, -3, 8], [10, 3, 60], (100, 3))
+    a, _ = synth.project(K, pose0[:3], pose0[3], Xt); b, _ = synth.project(K, pose2[:3], pose2[3], Xt)
+    Xr, rr, vr = oracle.triangulate_cam(a, b, oracle.camera_matrix(pose0, K), oracle.camera_matrix(pose2, K))
+    assert vr.all() and np.abs(Xr - Xt).max() < 1e-7 and rr.max() < 1e-8
+
+
 def test_reprojection_error_is_the_pixel_distance():
     R = synth.rot_y(3.0); C = np.array([0.1, 0.0, 0.5])
     X = np.array([[2.0, 1.0, 20.0], [-4.0, 0.5, 35.0]])

@@ -65,7 +65,7 @@ EXPORTS = [
     "vo_ctx_sync", "vo_ctx_lane_begin", "vo_ctx_lane_resume", "vo_ctx_lane_end", "vo_ctx_lane_join", "vo_ctx_lane_priority", "vo_dev_frame_wait", "vo_ctx_last_error", "vo_ctx_read_counters", "vo_stats_gather", "vo_timer_start", "vo_timer_stop_ms",
     "vo_timer_lap_begin", "vo_timer_lap_end", "vo_timer_laps_ms", "vo_ctx_time_score", "vo_ctx_read_score_tests",
     "vo_klt_track", "vo_select_candidates", "vo_harris_response", "vo_corner_response",
-    "vo_select_keypoints_greedy", "vo_triangulate_candidates", "vo_angle_deg", "vo_in_front", "vo_reproj_error",
+    "vo_select_keypoints_greedy", "vo_triangulate_candidates", "vo_triangulate_points", "vo_angle_deg", "vo_in_front", "vo_reproj_error",
     "vo_p3p_ransac", "vo_p3p_batch", "vo_essential_ransac", "vo_essential_ransac_five", "vo_dev_frame_build", "vo_dev_klt_track", "vo_dev_klt_track_head", "vo_dev_wait_head", "vo_dev_head_timed_out", "vo_dev_select_candidates", "vo_dev_select_begin", "vo_dev_select_finish",
     "vo_dev_frame_prefetch",
     "vo_dev_triangulate", "vo_dev_p3p_ransac", "vo_dev_p3p_ransac_static", "vo_dev_merge_ranks", "vo_frame_create", "vo_frame_destroy", "vo_frame_set_state",

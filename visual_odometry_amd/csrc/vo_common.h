@@ -148,6 +148,9 @@ int vo_launch_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1,
                           const double* d_pose1, const double* d_K, double* d_X, vo_strides sX,
                           double* d_reproj, double* d_angle, uint8_t* d_valid,
                           const int32_t* d_C = nullptr);   // d_C: the candidate count on the device, C its upper bound
+int vo_launch_triangulate_cam(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, vo_strides sxy, const double* d_cam0,
+                              const double* d_cam1, int cam_col_major, int n, double* d_X, vo_strides sX, double* d_reproj,
+                              uint8_t* d_valid);
 int vo_launch_angle(vo_ctx* ctx, const double* d_X, vo_strides sX, int n, const double* d_pose0,
                     const double* d_pose1, int pose_col_major, double* d_angle);
 int vo_launch_in_front(vo_ctx* ctx, const double* d_cam, int cam_col_major, const double* d_X, vo_strides sX,

@@ -168,6 +168,50 @@ __global__ __launch_bounds__(256) void k_triangulate(TriArgs a) {
     a.angle[i] = angle_deg(Xi, pose0 + 9, s_pose1 + 9);
 }
 
+// The toolbox call itself, `triangulate(matchedPoints1, matchedPoints2, camMatrix1, camMatrix2)` as the reference makes
+// it (modules/VisualOdometry.m:97-101, modules/candidateTriangulation.m:47-51, processFrame.m:55-59): n point pairs, the
+// two 4 x 3 camera matrices given -- the same DLT rows, Jacobi and projections as k_triangulate, without the pose ->
+// camera-matrix step and without the bearing angle (two lanes per pair, svd4_last_pair).
+struct TriCamArgs {
+    const double *xy0, *xy1; vo_strides sxy; const double *cam0, *cam1; int cam_col_major, n;
+    double* X; vo_strides sX; double* reproj; uint8_t* valid;
+};
+__global__ __launch_bounds__(256) void k_triangulate_cam(TriCamArgs a) {
+    __shared__ double s_cam[24];
+    if (threadIdx.x < 2) {
+        double c[12];
+        load43(threadIdx.x ? a.cam1 : a.cam0, a.cam_col_major, c);
+        for (int k = 0; k < 12; ++k) s_cam[12 * threadIdx.x + k] = c[k];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 128 + (threadIdx.x >> 1);
+    const int role = threadIdx.x & 1;
+    if (i >= a.n) return;
+    double cam0[12], cam1[12];
+    for (int k = 0; k < 12; ++k) { cam0[k] = s_cam[k]; cam1[k] = s_cam[12 + k]; }
+    const double x0 = a.xy0[i * a.sxy.xi], y0 = a.xy0[i * a.sxy.xi + a.sxy.xc];
+    const double x1 = a.xy1[i * a.sxy.xi], y1 = a.xy1[i * a.sxy.xi + a.sxy.xc];
+    double A[16], h[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        A[0 * 4 + k] = x0 * cam0[k * 3 + 2] - cam0[k * 3 + 0];
+        A[1 * 4 + k] = y0 * cam0[k * 3 + 2] - cam0[k * 3 + 1];
+        A[2 * 4 + k] = x1 * cam1[k * 3 + 2] - cam1[k * 3 + 0];
+        A[3 * 4 + k] = y1 * cam1[k * 3 + 2] - cam1[k * 3 + 1];
+    }
+    svd4_last_pair(A, role, h);
+    if (role) return;
+    double Xi[3] = {h[0] / h[3], h[1] / h[3], h[2] / h[3]};
+    double u, v, w0, w1;
+    project(cam0, Xi, u, v, w0);
+    const double e0 = sqrt((u - x0) * (u - x0) + (v - y0) * (v - y0));
+    project(cam1, Xi, u, v, w1);
+    const double e1 = sqrt((u - x1) * (u - x1) + (v - y1) * (v - y1));
+    for (int c = 0; c < 3; ++c) a.X[i * a.sX.xi + c * a.sX.xc] = Xi[c];
+    a.reproj[i] = 0.5 * (e0 + e1);
+    a.valid[i] = (uint8_t)(w0 > 0.0 && w1 > 0.0);
+}
+
 __global__ __launch_bounds__(256) void k_angle(const double* X, vo_strides sX, int n, const double* pose0,
                                                const double* pose1, int pose_col_major, double* out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -218,6 +262,18 @@ int vo_launch_triangulate(vo_ctx* ctx, const double* d_xy0, const double* d_xy1,
     a.pose_idx = d_pose_idx; a.C = C; a.P = P; a.pose1 = d_pose1; a.K = d_K; a.X = d_X; a.sX = sX;
     a.reproj = d_reproj; a.angle = d_angle; a.valid = d_valid; a.C_dev = d_C;
     hipLaunchKernelGGL(k_triangulate, dim3((C + 127) / 128), dim3(256), 0, ctx->stream, a);
+    VO_HIP_CHECK(ctx, hipGetLastError());
+    return VO_OK;
+}
+
+int vo_launch_triangulate_cam(vo_ctx* ctx, const double* d_xy0, const double* d_xy1, vo_strides sxy, const double* d_cam0,
+                              const double* d_cam1, int cam_col_major, int n, double* d_X, vo_strides sX, double* d_reproj,
+                              uint8_t* d_valid) {
+    if (n <= 0) return VO_OK;
+    TriCamArgs a;
+    a.xy0 = d_xy0; a.xy1 = d_xy1; a.sxy = sxy; a.cam0 = d_cam0; a.cam1 = d_cam1; a.cam_col_major = cam_col_major; a.n = n;
+    a.X = d_X; a.sX = sX; a.reproj = d_reproj; a.valid = d_valid;
+    hipLaunchKernelGGL(k_triangulate_cam, dim3((n + 127) / 128), dim3(256), 0, ctx->stream, a);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }

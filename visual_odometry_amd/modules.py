@@ -78,6 +78,16 @@ def isInFrontOfCamera(camMat, points3d):
     return ops.in_front(camMat, points3d)
 
 
+def triangulate(matchedPoints1, matchedPoints2, camMatrix1, camMatrix2):
+    """The toolbox call at modules/VisualOdometry.m:97-101 / modules/candidateTriangulation.m:47-51 / processFrame.m:55-59:
+    N x 2 points, 4 x 3 camera matrices -> (worldPoints N x 3, reprojectionErrors N, validIndex N); outputs follow the
+    class of the points (matlab/triangulate.m does the same)."""
+    p1 = np.asarray(matchedPoints1)
+    dt = np.float32 if p1.dtype == np.float32 else np.float64
+    X, rep, valid = ops.triangulate(p1, matchedPoints2, camMatrix1, camMatrix2)
+    return X.astype(dt), rep.astype(dt), valid
+
+
 def estimateWorldCameraPose(imagePoints, worldPoints, cameraParams, MaxNumTrials=1000, Confidence=99,
                             MaxReprojectionError=1, Seed=1023, SampleIdx=None):
     """The pose step's toolbox call (modules/VisualOdometry.m:285-289): P3P inside MSAC.

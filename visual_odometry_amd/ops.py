@@ -157,6 +157,25 @@ def triangulate_candidates(first_xy, curr_xy, first_poses, curr_pose, K, first_p
     return X, rep, ang, val.astype(bool)
 
 
+def triangulate(matchedPoints1, matchedPoints2, camMatrix1, camMatrix2, col_major=False, ctx=None):
+    """The toolbox call as the reference makes it (modules/VisualOdometry.m:97-101, modules/candidateTriangulation.m:47-51,
+    processFrame.m:55-59): N x 2 point pairs and two 4 x 3 camera matrices -> (worldPoints N x 3, reprojectionErrors N,
+    validIndex N).  One C-ABI call (vo_triangulate_points); the batched form over per-candidate first poses is
+    triangulate_candidates."""
+    ctx = ctx or Context.default()
+    cm = 1 if col_major else 0
+    a = _mat(matchedPoints1, cm, np.float64, 2)
+    b = _mat(matchedPoints2, cm, np.float64, 2)
+    n = a.shape[0]
+    if b.shape[0] != n:
+        raise ValueError("matchedPoints1 and matchedPoints2 differ in length")
+    c0, c1 = _pose(camMatrix1, cm), _pose(camMatrix2, cm)      # 4 x 3, the call's layout
+    X = _empty(n, 3, cm, np.float64)
+    rep = np.zeros(n); val = np.zeros(n, np.uint8)
+    ctx.call("vo_triangulate_points", Layout(cm, 1), ptr(a), ptr(b), n, ptr(c0), ptr(c1), ptr(X), ptr(rep), ptr(val))
+    return X, rep, val.astype(bool)
+
+
 def angle_deg(landmarks, pose0, pose1, col_major=False, ctx=None):
     """utils/calculateAngleDeg.m:1-11 batched over landmarks."""
     ctx = ctx or Context.default()
