@@ -222,6 +222,44 @@ def test_triangulation_from_camera_matrices_is_the_same_triangulation():
     assert vr.all() and np.abs(Xr - Xt).max() < 1e-7 and rr.max() < 1e-8
 
 
+def test_triangulation_against_a_numpy_svd_restatement():
+    """Second, independent restatement of the two-view DLT (modules/VisualOdometry.m:93-101, old/linearTriangulation.m:28-39)
+    on NOISY observations: camera matrices by plain matrix products, the null vector by numpy's SVD (LAPACK) instead of
+    the oracle's one-sided Jacobi, error and validity from the projections.  The oracle's Jacobi order and stopping rule
+    were redefined together with the kernel once (round 1); this holds the result, not the path to it."""
+    xy0, xy1, poses0, pose1, _ = synth.triangulation_scene(400, noise=0.5)
+    Xe, rep, ang, valid = oracle.triangulate(xy0, xy1, poses0, pose1, K)
+
+    def cam(pose):                                       # [Rext; text] * K^T with Rext = R^T, text = -t R^T (SURVEY 8)
+        R, t = pose[:3], pose[3]
+        return np.vstack([R.T, -t @ R.T]) @ K.T
+
+    c1 = cam(pose1)
+    worst = 0.0
+    for i in range(len(xy0)):
+        c0 = cam(poses0[i].reshape(4, 3))
+        P0, P1 = c0.T, c1.T                              # 3 x 4
+        A = np.stack([xy0[i, 0] * P0[2] - P0[0], xy0[i, 1] * P0[2] - P0[1], xy1[i, 0] * P1[2] - P1[0], xy1[i, 1] * P1[2] - P1[1]])
+        s = np.linalg.svd(A)[1]
+        h = np.linalg.svd(A)[2][-1]
+        X = h[:3] / h[3]
+        e = []
+        w = []
+        for c, xy in ((c0, xy0[i]), (c1, xy1[i])):
+            p = np.append(X, 1.0) @ c
+            w.append(p[2]); e.append(np.hypot(p[0] / p[2] - xy[0], p[1] / p[2] - xy[1]))
+        if s[2] / s[0] < 1e-9:                           # (near-)zero baseline: the null space is not a line
+            continue
+        worst = max(worst, np.abs(Xe[i] - X).max() / max(1.0, np.abs(X).max()))
+        assert abs(rep[i] - 0.5 * (e[0] + e[1])) < 1e-6 * max(1.0, rep[i])
+        if min(abs(w[0]), abs(w[1])) > 1e-6:
+            assert valid[i] == (w[0] > 0 and w[1] > 0)
+        d0, d1 = X - poses0[i].reshape(4, 3)[3], X - pose1[3]
+        cosang = np.clip(d0 @ d1 / (np.linalg.norm(d0) * np.linalg.norm(d1)), -1, 1)
+        assert abs(ang[i] - np.degrees(np.arccos(cosang))) < 1e-6
+    assert worst < 1e-9, worst                           # 2e-12 observed
+
+
 def test_reprojection_error_is_the_pixel_distance():
     R = synth.rot_y(3.0); C = np.array([0.1, 0.0, 0.5])
     X = np.array([[2.0, 1.0, 20.0], [-4.0, 0.5, 35.0]])
