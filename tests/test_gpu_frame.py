@@ -307,6 +307,37 @@ def test_large_states_take_one_wave_compactions_with_the_same_bits(ctx, depth, m
         loop.close()
 
 
+def test_a_compaction_wait_that_gives_up_is_reported(ctx, monkeypatch):
+    """The one-wave compactions wait for counts that the workgroups in front of them publish; a wait gives up after a
+    bounded number of looks so that the grid always drains.  That cannot happen in a correct run -- and if it ever does
+    the frame's counts are wrong, which the caller must hear about instead of getting a plausible pose: the wait raises a
+    word in pinned host memory and vo_frame_collect returns an error.  Injected here (VO_FRAME_FAULT_INJECT, read when
+    a loop is created: the first workgroup of the next tracked-landmark compaction stays silent); afterwards a freshly
+    loaded state runs as if nothing had happened -- same bits as a loop that never saw the fault."""
+    KK = synth.KITTI_K
+    frames, poses, lift = synth.plane_sequence(4, KK, nv=376, nu=1241, depth=20.0, step=(0.2, 0.0, 0.15))
+    st0 = synth.stress_state(KK, lift, vo_frame.new_state, 3000, 3000, max_age=20)
+    kw = dict(maxNumLandmarks=3000, maxCandidates=6000, CandidatesToKeep=400, MinDistance=3.0, angularThreshold=12.0,
+              maxTemporalRecall=24)
+    clean = FrameLoop(KK, frames[0].shape, ctx=ctx, **kw)
+    clean.set_state(st0, frames[0])
+    want = [clean.processFrame(frames[k]) for k in (1, 2)]
+    want_final = clean.get_state()
+    clean.close()
+    monkeypatch.setenv("VO_FRAME_FAULT_INJECT", "1")
+    loop = FrameLoop(KK, frames[0].shape, ctx=ctx, **kw)
+    monkeypatch.delenv("VO_FRAME_FAULT_INJECT", raising=False)
+    loop.set_state(st0, frames[0])
+    with pytest.raises(_lib.VoError, match="gave up"):
+        loop.processFrame(frames[1])
+    loop.set_state(st0, frames[0])                       # the injection was for one launch: the loop is usable again
+    got = [loop.processFrame(frames[k]) for k in (1, 2)]
+    for (p0, s0, i0), (p1, s1, i1) in zip(got, want):
+        assert np.array_equal(p0, p1) and s0 == s1 and i0 == i1
+    assert states_equal(loop.get_state(), want_final)
+    loop.close()
+
+
 def synth_lift_at(pose, u, v, depth=12.0):
     """landmarks on the plane Z = depth seen at pixel (u, v) from `pose` ([R_cw; C])"""
     R, C = pose[:3], pose[3]

@@ -97,7 +97,7 @@ int vo_launch_klt(vo_ctx* ctx, const vo_pyr* A, const vo_pyr* B, const double* d
                   uint8_t* d_valid, float* d_score, float* d_fb,
                   const int32_t* d_n = nullptr,    // d_n: the keypoint count on the device, n its upper bound
                   int n_head = 0);                 // > 0: the first n_head keypoints are a head (vo_dev_klt_track_head)
-int vo_launch_wait_head(vo_ctx* ctx, const int32_t* d_n = nullptr);   // ctx->stream waits (a polling kernel) for the last head launched (d_n: that launch's device count)
+int vo_launch_wait_head(vo_ctx* ctx, const int32_t* d_n = nullptr, int32_t* host_fault = nullptr);   // ctx->stream waits (a polling kernel) for the last head launched (d_n: that launch's device count; host_fault: a pinned host word that receives 2 when the wait gives up)
 // three words of the ctx for the head of a tracking launch: arrival count, flag (epoch of the last finished head), time-out
 // (vo_int_head_words, above)
 

@@ -78,7 +78,10 @@ __global__ __launch_bounds__(1024) void k_compact2(OpA a, int na, int32_t* count
 // writes the total.  The epoch (a host counter, one per launch) tells this launch's words from an earlier one's, so the
 // words are never cleared; a poll gives up after CW_SPINS looks, so the grid drains whatever happens.
 constexpr int CW_EPL = 8, CW_BLOCK = 64 * CW_EPL, CW_MAX_BLOCKS = 256, CW_SITES = 8, CW_SPINS = 1 << 20;
-struct Chain { unsigned long long* w; unsigned epoch; };
+// fault: a word in pinned host memory that a poll which gives up raises (vo_frame_collect reports it: the frame's counts
+// are then not to be trusted); skip: the workgroup that does NOT publish, -1 in every real launch (fault injection of
+// tests/test_gpu_frame.py, VO_FRAME_FAULT_INJECT)
+struct Chain { unsigned long long* w; unsigned epoch; int32_t* fault; int skip; };
 __device__ __forceinline__ int wave_sum_i(int x) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
@@ -86,7 +89,7 @@ __device__ __forceinline__ int wave_sum_i(int x) {
 }
 __device__ __forceinline__ int chain_exclusive(const Chain& c, int b, int tot) {
     const int lane = threadIdx.x;
-    if (lane == 0)
+    if (lane == 0 && b != c.skip)
         __hip_atomic_store(&c.w[b], ((unsigned long long)c.epoch << 32) | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int sum = 0;
     for (int j = lane; j < b; j += 64) {
@@ -95,6 +98,10 @@ __device__ __forceinline__ int chain_exclusive(const Chain& c, int b, int tot) {
             v = __hip_atomic_load(&c.w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)(v >> 32) == c.epoch) break;
             __builtin_amdgcn_s_sleep(2);
+        }
+        if ((unsigned)(v >> 32) != c.epoch) {   // gave up: the count is unknown (taken as 0: every position stays inside the arrays)
+            v = 0;
+            if (c.fault) __hip_atomic_store(c.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         sum += (int)(unsigned)v;
     }
@@ -836,6 +843,8 @@ struct vo_frame_state {
     int32_t* sizes;                         // device: {landmarks, candidates} of state s (k_append_new / set_state)
     unsigned long long* chain;              // the wide compactions' count words: CW_SITES call sites x CW_MAX_BLOCKS (zeroed once)
     unsigned chain_epoch = 0;               // one per wide compaction launched
+    int32_t* h_fault = nullptr;             // pinned: raised by a device-side wait that gave up (Chain::fault, k_wait_head); read by vo_frame_collect
+    bool fault_inject = false;              // VO_FRAME_FAULT_INJECT=1 (tests): one compaction workgroup of the next wide frame does not publish its count
     int32_t* h_counts;                      // pinned
     double* h_rec;                          // pinned: VO_FRAME_MAX_PENDING records of 40 doubles (ransac record 16, pose 12, counters)
     // host images go through a ring of pinned slots (one per pending frame + the look-ahead + one): the caller's buffer
@@ -988,6 +997,9 @@ int vo_frame_create(vo_ctx* ctx, const vo_frame_opts* o, int nu, int nv, const d
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[0], vo_int_event_flags());
     if (e == hipSuccess) e = hipEventCreateWithFlags(&st->ev_detect[1], vo_int_event_flags());
+    if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_fault, 64, 0);
+    if (e == hipSuccess) memset(st->h_fault, 0, 64);
+    st->fault_inject = getenv("VO_FRAME_FAULT_INJECT") != nullptr;
     if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_counts, 16 * sizeof(int32_t), 0);
     if (e == hipSuccess) e = hipHostMalloc((void**)&st->h_rec, VO_FRAME_MAX_PENDING * 40 * sizeof(double), 0);
     for (int k = 0; k < VO_FRAME_MAX_PENDING && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&st->ev_rec[k], hipEventDisableTiming);
@@ -1021,6 +1033,7 @@ int vo_frame_destroy(vo_ctx* ctx, vo_frame_state* st) {
     if (st->ev_ltrack) (void)hipEventDestroy(st->ev_ltrack);
     for (int k = 0; k < 2; ++k) if (st->ev_detect[k]) (void)hipEventDestroy(st->ev_detect[k]);
     for (int k = 0; k < VO_FRAME_MAX_PENDING; ++k) if (st->ev_rec[k]) (void)hipEventDestroy(st->ev_rec[k]);
+    if (st->h_fault) (void)hipHostFree(st->h_fault);
     if (st->h_counts) (void)hipHostFree(st->h_counts);
     if (st->h_rec) (void)hipHostFree(st->h_rec);
     for (int r = 0; r < vo_frame_state::PIN_SLOTS; ++r) {
@@ -1240,7 +1253,9 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     const bool wide = (cl > st->wide_min || cc > st->wide_min) && cw_blocks(pw) <= CW_MAX_BLOCKS && !st->narrow;
     auto chain = [&](int site) {
         if (++st->chain_epoch == 0) ++st->chain_epoch;     // 0 is what a never-written word holds
-        return Chain{st->chain + (size_t)site * CW_MAX_BLOCKS, st->chain_epoch};
+        int skip = -1;
+        if (st->fault_inject && site == 0) { skip = 0; st->fault_inject = false; }   // (tests: the first workgroup of the next tracked-landmark compaction stays silent)
+        return Chain{st->chain + (size_t)site * CW_MAX_BLOCKS, st->chain_epoch, st->h_fault, skip};
     };
     auto stamp = [&](hipStream_t q, int id) {
         if (st->h_stamps && frame_no < STAMP_FRAMES && ((st->stamp_mask >> id) & 1)) hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, q, st->h_stamps + (size_t)frame_no * STAMP_N + id);
@@ -1307,7 +1322,7 @@ int vo_frame_submit(vo_ctx* ctx, vo_frame_state* st, const uint8_t* img, int on_
     // :71 track the candidates: points from the state, results straight into the candidates' work arrays
     if (l_first) {
         if (st->l_head_pct >= 100) ST_CHECK(hipStreamWaitEvent(sm, st->ev_ltrack, 0));
-        else if ((rc = vo_launch_wait_head(ctx, st->sizes + 0))) return rc;      // (ctx->stream is sm again)
+        else if ((rc = vo_launch_wait_head(ctx, st->sizes + 0, st->h_fault))) return rc;      // (ctx->stream is sm again)
     }
     if ((rc = vo_launch_klt(ctx, &st->pyr[a], &st->pyr[b], st->cu[s], st->cu[s] + cc, cc, o.klt.block_w, o.klt.block_h,
                             o.klt.max_iters, eps, o.klt.max_bidir_err, st->cq, st->cq + cc, st->cvalid, /* :71 `~` */ nullptr, nullptr, st->sizes + 1))) return rc;
@@ -1468,6 +1483,14 @@ int vo_frame_collect(vo_ctx* ctx, vo_frame_state* st, double pose43[12], vo_fram
     info->frame_no = st->pend_frame_no[ps];
     st->nL = std::min(st->h_counts[0], st->capL); st->nC = st->h_counts[3];
     st->pend_head = (ps + 1) % VO_FRAME_MAX_PENDING; --st->pend_count;
+    // A device-side wait of this frame (or of one submitted behind it) gave up: an ordered compaction did not see a
+    // count it needed within CW_SPINS looks, or the candidates' launch never saw the head of the landmarks'.  The
+    // grid drained and nothing was written outside the arrays, but counts and order are not the reference's: say so.
+    if (const int32_t f = __atomic_exchange_n(st->h_fault, 0, __ATOMIC_RELAXED)) {
+        ctx->last_error = f == 2 ? "frame: the wait for the head of the landmarks' tracking launch gave up; the frame's result is not valid (load a state again)"
+                                 : "frame: a compaction's wait for a workgroup's count gave up; the frame's result is not valid (load a state again)";
+        return VO_ERR_HIP;
+    }
     return VO_OK;
 }
 

@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64, C::WAVES) void k_lk(LKArgs a) {
 // The consumers' side of a head (vo_dev_wait_head): one lane polls the flag until the launch's epoch is there.  Bounded:
 // after ~0.25 s of polling it gives up and raises *timed_out (the launch it waits for was never enqueued, or sits behind
 // this kernel in the same hardware queue) -- every wave of this kernel reaches its end whatever happens.
-__global__ __launch_bounds__(64) void k_wait_head(const unsigned* flag, unsigned epoch, unsigned* timed_out, const int32_t* n_dev) {
+__global__ __launch_bounds__(64) void k_wait_head(const unsigned* flag, unsigned epoch, unsigned* timed_out, const int32_t* n_dev, int32_t* host_fault) {
     if (threadIdx.x != 0) return;
     if (n_dev && *n_dev <= 0) return;   // the launch had no keypoint at all (its count lives on the device): nobody arrives
     for (int spin = 0; spin < 250000; ++spin) {
@@ -684,6 +684,7 @@ __global__ __launch_bounds__(64) void k_wait_head(const unsigned* flag, unsigned
         __builtin_amdgcn_s_sleep(32);   // ~2k cycles: the poll costs the memory system nothing
     }
     __hip_atomic_store(timed_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (host_fault) __hip_atomic_store(host_fault, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // pinned host word of the frame loop
 }
 
 template <class C, bool SCORE>
@@ -700,9 +701,9 @@ void launch(const LKArgs& a, hipStream_t st) {
 
 } // namespace
 
-int vo_launch_wait_head(vo_ctx* ctx, const int32_t* d_n) {
+int vo_launch_wait_head(vo_ctx* ctx, const int32_t* d_n, int32_t* host_fault) {
     unsigned* w = reinterpret_cast<unsigned*>(vo_int_head_words(ctx));
-    hipLaunchKernelGGL(k_wait_head, dim3(1), dim3(64), 0, ctx->stream, w + 1, ctx->head_epoch, w + 2, d_n);
+    hipLaunchKernelGGL(k_wait_head, dim3(1), dim3(64), 0, ctx->stream, w + 1, ctx->head_epoch, w + 2, d_n, host_fault);
     VO_HIP_CHECK(ctx, hipGetLastError());
     return VO_OK;
 }
