@@ -17,6 +17,7 @@ seed-offset sequence (weak scaling, no data-path collective); RCCL gathers the s
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -359,6 +360,13 @@ def main():
     wl.sync(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     dist.barrier()
+    # the pose chain of a step starts behind a bounded device-side wait for the head of the tracking launch: had it ever
+    # given up, the steps timed above would not be the workload -- say so and fail instead of printing a number
+    head_gave_up = C.c_int(0)
+    ctx.call("vo_dev_head_timed_out", C.byref(head_gave_up))
+    if head_gave_up.value:
+        print("bench.py: a wait for the head of a tracking launch gave up during the timed steps; no result", file=sys.stderr)
+        sys.exit(3)
     valid = int(wl.vl.sum().item()) + int(wl.vc.sum().item())
     inl = int(wl.rs_inl.sum().item())
     stats = dist.gather_stats({"frames": args.steps, "keypoints_tracked": args.steps * args.keypoints,
