@@ -439,7 +439,6 @@ def main():
         # the scene; the timed steps score the scene of SURVEY 8d, 20 % outliers)
         pose_chain = None
         try:
-            import ctypes as C
             import numpy as np
             from visual_odometry_amd import synth
             ctx.call("vo_ctx_time_score", 1)
