@@ -44,5 +44,7 @@ for (g, beside), v in sorted(d.items()):
     print("k_lk grid %8d (%6d keypoints), %-28s: %5d launches, average %9.1f ns, median %9.1f ns, min %9.1f ns"
           % (g, g // 64, "pose chain beside it" if beside else "alone on the chip", len(v), sum(v) / len(v), v[len(v) // 2], v[0]))
 PY
+# the un-profiled bench line quotes traffic / valu_util from the PMC summary of THIS run (same box, same sources)
+cp $O/k_lk_pmc.json $R/profiles/round3_k_lk_pmc.json
 timeout -k 10 400 python3 bench.py --steps 50 --warmup 5 > $O/bench.json
 cat $O/k_lk_pmc.txt; cat $O/k_lk_by_grid.txt; head -8 $O/kernel_stats.csv | cut -c1-160; cat $O/bench.json
