@@ -333,6 +333,10 @@ def main():
         print("bench.py: no HIP device (there is no CPU fallback)", file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
+    # the communicator is set up by its first collective (seconds, with the GPU idle): here, in front of the spin-up, and
+    # not inside the barrier that opens the timed region -- the steps behind that one would start on a device whose
+    # clocks have come down (the first few hundred milliseconds after an idle period run ~3 % slower, below)
+    dist.barrier()
     ctx = _lib.Context(local_rank)
     nl = args.keypoints // 2
     nc = args.keypoints - nl
