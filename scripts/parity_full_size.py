@@ -43,5 +43,38 @@ for mode in (1, 0):
     print(f"  own hypotheses (device P3P, libm ulps apart): same record {(own['best_hyp'], own['best_sol']) == (o['best_hyp'], o['best_sol'])}, "
           f"{(own['counts'] == o['counts']).mean() * 100:.2f} % of the per-pose counts equal, inlier sets differ in {(own['inliers'] != o['inliers']).sum()} points")
     ok = ok and same
+# ---- optional (--chain N: minutes of oracle time, not part of the test): N frames of the device-resident loop at the
+# stress size (25 000 landmarks at the cap + 25 000 seeded candidates, CandidatesToKeep 5000), the state never leaving
+# HBM between frames; the oracle's sequential processFrame steps from the state the device held before each frame
+if "--chain" in sys.argv:
+    from oracle import vo_frame
+    from visual_odometry_amd.frame import FrameLoop
+    n_chain = int(sys.argv[sys.argv.index("--chain") + 1])
+    frames, poses, lift = synth.plane_sequence(n_chain + 1, K, nv=376, nu=1241, depth=20.0, step=(0.2, 0.0, 0.15))
+    kw = dict(maxNumLandmarks=25000, CandidatesToKeep=5000, MinDistance=1.5, angularThreshold=12.0, maxTemporalRecall=24)
+    prev = synth.stress_state(K, lift, vo_frame.new_state, max_age=20)
+    loop = FrameLoop(K, frames[0].shape, maxCandidates=32000, **kw)       # room for the new candidates: the reference's arrays grow
+    loop.set_state(prev, frames[0])
+    for k in range(1, n_chain + 1):
+        gpose, gstatus, ginfo = loop.processFrame(frames[k])
+        g = loop.get_state()
+        t0 = time.perf_counter()
+        o, pose, status, info = vo_frame.process_frame(frames[k - 1], frames[k], prev, K, k, maxNumLandmarks=25000, keep=5000, min_distance=1.5,
+                                                       angularThreshold=12.0, maxTemporalRecall=24, threads=THREADS)
+        t_or = time.perf_counter() - t0
+        same_counts = (ginfo["n_tracked"], ginfo["n_promoted"], ginfo["n_new"], len(g.landmarks), len(g.candidate_keypoints)) == \
+                      (info["tracked"], info["promoted"], info["new"], len(o.landmarks), len(o.candidate_keypoints))
+        dpose = np.abs(gpose - pose).max()
+        dk = np.abs(g.keypoints - o.keypoints).max() if same_counts else float("nan")
+        dl = (np.abs(g.landmarks - o.landmarks) / np.maximum(1.0, np.abs(o.landmarks))).max() if same_counts else float("nan")
+        same_ids = same_counts and np.array_equal(g.candidate_first_keypoints, o.candidate_first_keypoints) and \
+            np.array_equal(g.candidate_time_indxs, o.candidate_time_indxs)
+        print(f"frame {k}: {ginfo['n_tracked']} landmarks + {len(prev.candidate_keypoints)} candidates tracked, {ginfo['n_promoted']} promoted "
+              f"({info['replaced']} replaced a landmark at the cap), {ginfo['n_new']} new; counts {'equal' if same_counts else 'DIFFER'}, "
+              f"candidate identities and ages {'equal' if same_ids else 'DIFFER'}, |pose| {dpose:.1e}, keypoints {dk:.1e} px, landmarks {dl:.1e} rel "
+              f"(oracle {t_or:.1f} s)", flush=True)
+        ok = ok and same_counts and same_ids and gstatus == status == 0 and dpose < 1e-4 and dk < 0.01 and dl < 1e-4
+        prev = g
+    loop.close()
 print("FULL-SIZE PARITY:", "ok" if ok else "FAILED")
 sys.exit(0 if ok else 1)
