@@ -189,8 +189,11 @@ def frame_loop_leg(ctx, with_cpu, n_frames=24):
     # would ever pass the filter.  The candidates are seeded: first seen 1 .. 20 frames before frame 0 (poses extrapolated
     # backwards along the track, first keypoints = their projections there); with the angular threshold at 12 degrees
     # (0.57 degrees of parallax a frame at this depth) a cohort of 1 250 becomes promotable every frame, each promotion
-    # replacing the worst landmark at the cap, and the detector finds 500 - 1 800 new corners a frame (a 1241 x 376 frame
-    # holds ~13k corners of this detector: the seeded 50k settle towards what the scene can feed, see keypoints_mean).
+    # replacing the worst landmark at the cap, and 500 - 1 800 new candidates are appended a frame: while the candidate
+    # arrays are full (maxCandidates = the seeded 25 000; the first eight frames, `overflow` set in their records) as many
+    # as promotions and expiries make room for, afterwards what the scene feeds (a 1241 x 376 frame holds ~13k corners of
+    # this detector, 500 - 800 of them new a frame: the seeded 50k settle towards that, see keypoints_mean;
+    # scripts/stress_counts.py prints the counts frame by frame, with and without room).
     n_l = n_c = 25000
     st5 = synth.stress_state(K, lift, modules._new_state, n_l, n_c, max_age=20)
     loop5 = FrameLoop(K, frames[0].shape, maxNumLandmarks=n_l, maxCandidates=n_c, CandidatesToKeep=5000, MinDistance=1.5,
@@ -217,7 +220,8 @@ def frame_loop_leg(ctx, with_cpu, n_frames=24):
                                            "promotable a frame), CandidatesToKeep 5000, MinDistance 1.5 px (at 7 px a KITTI frame has "
                                            "no room for 50k points), everything else as above; the merge is the sort-based form, the "
                                            "compactions the one-wave form; keypoints_mean = keypoints tracked per frame over the "
-                                           "pass (the scene feeds fewer new corners than expire); frames_per_s from the median pass"}
+                                           "pass (new candidates: as many as there is room for while the candidate arrays are full -- the first eight frames --, then "
+                                           "what the scene feeds, fewer than expire); frames_per_s from the median pass"}
     if with_cpu:                                          # cpu_baseline of this leg: the oracle's restatement
         from oracle import vo_frame
         threads = min(16, os.cpu_count() or 1)
