@@ -33,6 +33,10 @@ __global__ __launch_bounds__(64) void k(unsigned long long* stamps, float* out, 
             asm volatile("v_sub_f32 %0, %1, %0\n v_fma_f32 %0, %0, %8, %1\n v_sub_f32 %2, %3, %2\n v_fma_f32 %2, %2, %8, %3\n"
                          "v_sub_f32 %4, %5, %4\n v_fma_f32 %4, %4, %8, %5\n v_sub_f32 %6, %7, %6\n v_fma_f32 %6, %6, %8, %7\n"
                          : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+        } else if (MODE == 4) { // 8 independent v_pk_fma_f32 (two fp32 FMAs per lane and instruction) on the fp64 registers' pairs
+            asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n"
+                         "v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(da), "v"(db));
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -80,6 +84,7 @@ int main() {
         run<1>("v_fma_f32 chain", d_st, d_out, w, iters);
         run<3>("v_sub+v_fma pairs", d_st, d_out, w, iters);
         run<2>("v_fma_f64 indep", d_st, d_out, w, iters / 2);
+        run<4>("v_pk_fma_f32 indep", d_st, d_out, w, iters / 2);
     }
     return 0;
 }
