@@ -120,3 +120,32 @@ def test_name_value_options_of_the_shadows_are_the_references():
         if os.path.exists(ref_path):
             ref_names = re.findall(r"^\s*\w+\.(\w+)\s.*=", open(ref_path).read(), flags=re.M)
             assert [n for n in ref_names if n in names] == names, (f, ref_names)
+
+
+def test_every_gateway_a_shadow_calls_exists_and_takes_that_many_arguments():
+    """matlab/*.m call `vo_*_mex(...)`: the gateway's source is in mex/, and the number of arguments of the call is the
+    one the gateway's `nrhs` check accepts (a gateway says `nrhs != N` or `nrhs < A || nrhs > B` in its first lines)."""
+    calls = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "matlab", "*.m"))):
+        text = re.sub(r"\.\.\.[^\n]*\n", " ", open(f).read())
+        text = "\n".join(l.split("%")[0] for l in text.splitlines())          # comments
+        for m in re.finditer(r"\b(vo_[a-z0-9_]+_mex)\s*\(", text):
+            depth, i, n = 1, m.end(), 1
+            while depth and i < len(text):
+                ch = text[i]
+                depth += ch in "([{"; depth -= ch in ")]}"
+                n += ch == "," and depth == 1
+                i += 1
+            calls.append((os.path.basename(f), m.group(1), n))
+    assert len(calls) >= 6, calls
+    for shadow, gw, nargs in calls:
+        src = os.path.join(ROOT, "mex", gw + ".cpp")
+        assert os.path.exists(src), f"{shadow} calls {gw}, which mex/ does not hold"
+        code = open(src).read()
+        m = re.search(r"nrhs\s*!=\s*(\d+)", code)
+        if m:
+            assert nargs == int(m.group(1)), f"{shadow}: {gw} called with {nargs} arguments, the gateway takes {m.group(1)}"
+            continue
+        m = re.search(r"nrhs\s*<\s*(\d+)\s*\|\|\s*nrhs\s*>\s*(\d+)", code)
+        if m:
+            assert int(m.group(1)) <= nargs <= int(m.group(2)), f"{shadow}: {gw} called with {nargs} arguments, the gateway takes {m.group(1)}..{m.group(2)}"
